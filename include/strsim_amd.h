@@ -1,0 +1,137 @@
+/*
+ * strsim_amd.h -- C ABI of the MI355X (gfx950) pairwise string-similarity library.
+ *
+ * This is the drop-in boundary for the hot path of foxcroftjn/polars-strsim: everything the
+ * reference computes inside `strsim::parallel_apply` (reference src/expressions/strsim.rs:41-107) and
+ * the five `SimilarityFunction::compute` bodies (:125-162, :180-245, :257-272, :286-308, :322-345).
+ *
+ * Two layers are exported from the same shared library (libpolars_strsim_amd.so):
+ *
+ *   1. the thin kernel ABI below (`strsim_*`): Arrow Utf8 offsets+values buffers in, f64 column out.
+ *      This is what a Rust host (the reference's `parallel_apply`) would bind through `extern "C"`
+ *      after flattening its `StringChunked` -- see INTEGRATION.md for the binding stub.
+ *   2. the Polars plugin ABI (`_polars_plugin_*`, include/polars_plugin_abi.h): the symbols the
+ *      reference's `#[polars_expr]` macro generates (reference src/expressions/mod.rs:8-31), so the
+ *      library can be dropped into the `polars_strsim` package directory unchanged.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions return a strsim_status_t
+ * (0 = OK) unless stated otherwise; on error a message is available from
+ * strsim_last_error_message() (thread-local).  Nothing here ever computes on the CPU: without a
+ * usable GPU every compute entry point fails with STRSIM_ERR_NO_DEVICE.
+ */
+#ifndef STRSIM_AMD_H
+#define STRSIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STRSIM_ABI_VERSION 0x00010000u /* major<<16 | minor */
+
+#if defined(__GNUC__)
+#define STRSIM_API __attribute__((visibility("default")))
+#else
+#define STRSIM_API
+#endif
+
+/* Mirrors `enum SimilarityFunctionType` (reference strsim.rs:9-15). */
+typedef enum strsim_measure {
+    STRSIM_LEVENSHTEIN   = 0, /* normalised Levenshtein similarity, strsim.rs:125-162 */
+    STRSIM_JARO          = 1, /* strsim.rs:180-245 */
+    STRSIM_JARO_WINKLER  = 2, /* strsim.rs:257-272 */
+    STRSIM_JACCARD       = 3, /* character-multiset Jaccard, strsim.rs:286-308 */
+    STRSIM_SORENSEN_DICE = 4, /* character-multiset Sorensen-Dice, strsim.rs:322-345 */
+    STRSIM_NUM_MEASURES  = 5
+} strsim_measure_t;
+
+typedef enum strsim_status {
+    STRSIM_OK              = 0,
+    STRSIM_ERR_SHAPE       = 1, /* reference ShapeMismatch, strsim.rs:48-52 */
+    STRSIM_ERR_ARG         = 2, /* null pointer / bad enum / bad size */
+    STRSIM_ERR_NO_DEVICE   = 3, /* no usable HIP device: there is no CPU fallback */
+    STRSIM_ERR_HIP         = 4, /* a HIP runtime call failed (message has the detail) */
+    STRSIM_ERR_OOM         = 5,
+    STRSIM_ERR_DTYPE       = 6, /* plugin ABI: input is not a string column (reference `.str()?`, strsim.rs:46-47) */
+    STRSIM_ERR_INTERNAL    = 7
+} strsim_status_t;
+
+typedef struct strsim_ctx strsim_ctx_t; /* one device + one stream + its workspace; not thread-safe: one ctx per thread */
+
+/* (major<<16)|minor of this ABI. */
+STRSIM_API uint32_t strsim_abi_version(void);
+
+/* NUL-terminated description of the last error raised on the calling thread ("" if none). */
+STRSIM_API const char *strsim_last_error_message(void);
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+STRSIM_API int strsim_device_count(void);
+
+/* Create a context on `device`.  `hip_stream` is a hipStream_t to enqueue on (e.g. the host
+ * framework's current stream); NULL makes the context create and own a non-blocking stream. */
+STRSIM_API int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx);
+STRSIM_API void strsim_ctx_destroy(strsim_ctx_t *ctx);
+
+/* The stream work is enqueued on (a hipStream_t). */
+STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
+
+/*
+ * Enqueue one pass of `measure` over two DEVICE-RESIDENT Utf8 column shards.
+ *
+ * Column layout (Arrow "u", rebased): `offsets` = uint32[rows+1] with offsets[0] == 0... (any
+ * monotone base is accepted), `values` = the packed UTF-8 bytes [0, offsets[rows]).  A side with
+ * rows == 1 is the "Utf8 literal" of strsim.rs:48-52 and is broadcast against every row of the
+ * other side (strsim.rs:61-66).  Otherwise a_rows must equal b_rows, else STRSIM_ERR_SHAPE.
+ * `out` = double[out_rows] on the same device, out_rows = max(a_rows, b_rows).
+ * Nulls are not seen here: like the reference's arity helpers the kernels compute on the bytes under
+ * every slot; validity is combined by the caller (the plugin layer does it).
+ *
+ * The call is asynchronous: it returns once the kernels are enqueued on the context's stream.
+ * Results are complete after strsim_ctx_synchronize() (or after later work on the same stream for
+ * rows whose strings are <= STRSIM_WAVE_PATH_MAX_BYTES; longer rows are finished inside
+ * strsim_ctx_synchronize()).
+ */
+STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
+                        const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
+                        const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
+                        double *out, uint64_t out_rows);
+
+/* Wait for everything enqueued through this context and surface any deferred error. */
+STRSIM_API int strsim_ctx_synchronize(strsim_ctx_t *ctx);
+
+/*
+ * Same contract with HOST-RESIDENT buffers: stages the shards to the device, runs the kernels and
+ * copies the f64 column back; synchronous.
+ */
+STRSIM_API int strsim_pairs_host(strsim_ctx_t *ctx, int measure,
+                      const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
+                      const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
+                      double *out, uint64_t out_rows);
+
+/* Row partition used to shard a column over `n` GPUs/ranks: the reference's split_offsets
+ * (strsim.rs:21-39).  Writes n (offset,len) pairs into out_offset_len[2*n]. */
+STRSIM_API void strsim_split_offsets(uint64_t len, uint64_t n, uint64_t *out_offset_len);
+
+/*
+ * Kernel timing for roofline accounting.  When enabled, every strsim_pairs_device() brackets its
+ * dominant (lane-per-pair) kernel and its wave-per-pair kernel with hipEvents on the context's stream.
+ * strsim_ctx_timing_read() synchronises and returns the accumulated milliseconds and launch counts
+ * since the last read, then resets them.
+ */
+STRSIM_API int strsim_ctx_timing_enable(strsim_ctx_t *ctx, int enable);
+STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms, uint64_t *lane_kernel_launches,
+                           double *wave_kernel_ms, uint64_t *wave_kernel_launches);
+
+/* Rows the last completed strsim_pairs_device() on this context routed to the wave-per-pair kernel
+ * (valid after strsim_ctx_synchronize()). */
+STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
+
+#define STRSIM_LANE_PATH_MAX_BYTES 32u   /* lane-per-pair kernels: both strings <= 32 bytes, ASCII */
+#define STRSIM_WAVE_PATH_MAX_BYTES 1024u /* wave-per-pair kernels: both strings <= 1024 bytes, any UTF-8 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRSIM_AMD_H */

@@ -1,0 +1,320 @@
+// strsim_capi.cpp -- the thin kernel ABI of include/strsim_amd.h: contexts, workspace, launch, timing.
+//
+// Host-side counterpart of the row loop in the reference's `parallel_apply`
+// (reference src/expressions/strsim.rs:41-107): shape rule, literal broadcast, row partition.
+// There is no CPU compute path in this library: without a HIP device every compute call fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "strsim_amd.h"
+#include "strsim_internal.h"
+#include "strsim_kernels.h"
+
+namespace strsim {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error in %s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    if (e == hipErrorOutOfMemory) return STRSIM_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return STRSIM_ERR_NO_DEVICE;
+    return STRSIM_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);    \
+    } while (0)
+
+} // namespace strsim
+
+using namespace strsim;
+
+struct strsim_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 0;
+    // workspace (grow-only)
+    unsigned long long *slowmask = nullptr;
+    size_t slowmask_cap = 0; // entries
+    // per-call deferred state: a ring of status words + event triples, so calls can be enqueued
+    // back to back without a host sync; the ring is drained by strsim_ctx_synchronize()
+    static constexpr int RING = 32;
+    DevStatus *status = nullptr;      // device, RING entries
+    DevStatus *status_host = nullptr; // pinned, RING entries
+    hipEvent_t ev[RING][3] = {};
+    bool slot_pending[RING] = {};
+    bool slot_timed[RING] = {};
+    int head = 0;
+    uint64_t last_wave_rows = 0;
+    // staging for strsim_pairs_host (grow-only device buffers)
+    void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[5] = {0, 0, 0, 0, 0};
+    // timing
+    bool timing = false;
+    double lane_ms = 0, wave_ms = 0;
+    uint64_t lane_launches = 0, wave_launches = 0;
+};
+
+static int ctx_set_device(strsim_ctx *c) { HIP_TRY(hipSetDevice(c->device)); return STRSIM_OK; }
+
+// Retire every pending slot (the stream must already be synchronised).
+static int ctx_drain(strsim_ctx *c)
+{
+    int rc = STRSIM_OK;
+    for (int k = 0; k < strsim_ctx::RING; ++k) {
+        const int s = (c->head + k) % strsim_ctx::RING; // oldest first
+        if (!c->slot_pending[s]) continue;
+        c->slot_pending[s] = false;
+        if (c->slot_timed[s]) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]));
+            HIP_TRY(hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]));
+            c->lane_ms += a; c->wave_ms += b;
+            c->lane_launches++; c->wave_launches++;
+            c->slot_timed[s] = false;
+        }
+        const DevStatus &st = c->status_host[s];
+        c->last_wave_rows = st.wave_rows;
+        if (st.huge_rows != 0 && rc == STRSIM_OK) {
+            set_error("%u row(s) hold a string longer than %u bytes (longest: %u bytes); the long-string pass is not "
+                      "available in this build",
+                      st.huge_rows, (unsigned)STRSIM_WAVE_PATH_MAX_BYTES, st.max_len);
+            rc = STRSIM_ERR_INTERNAL;
+        }
+    }
+    return rc;
+}
+
+static int ctx_reserve(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return STRSIM_OK;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return STRSIM_OK;
+}
+
+extern "C" {
+
+uint32_t strsim_abi_version(void) { return STRSIM_ABI_VERSION; }
+
+const char *strsim_last_error_message(void) { return g_last_error.c_str(); }
+
+int strsim_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n < 0 ? 0 : n;
+}
+
+int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
+{
+    if (!out_ctx) { set_error("strsim_ctx_create: out_ctx is NULL"); return STRSIM_ERR_ARG; }
+    *out_ctx = nullptr;
+    const int ndev = strsim_device_count();
+    if (ndev == 0) {
+        set_error("no HIP device is available; polars-strsim_amd has no CPU fallback");
+        return STRSIM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("strsim_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+        return STRSIM_ERR_ARG;
+    }
+    strsim_ctx *c = new (std::nothrow) strsim_ctx();
+    if (!c) { set_error("out of host memory"); return STRSIM_ERR_OOM; }
+    c->device = device;
+    int rc = ctx_set_device(c);
+    if (rc) { delete c; return rc; }
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipGetDeviceProperties"); }
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreateWithFlags"); }
+        c->own_stream = true;
+    }
+    e = hipMalloc((void **)&c->status, sizeof(DevStatus) * strsim_ctx::RING);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&c->status_host, sizeof(DevStatus) * strsim_ctx::RING, hipHostMallocDefault);
+    if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "status allocation"); }
+    memset(c->status_host, 0, sizeof(DevStatus) * strsim_ctx::RING);
+    *out_ctx = c;
+    return STRSIM_OK;
+}
+
+void strsim_ctx_destroy(strsim_ctx_t *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < strsim_ctx::RING; ++s)
+        for (int i = 0; i < 3; ++i)
+            if (c->ev[s][i]) (void)hipEventDestroy(c->ev[s][i]);
+    for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
+    if (c->slowmask) (void)hipFree(c->slowmask);
+    if (c->status) (void)hipFree(c->status);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *strsim_ctx_stream(strsim_ctx_t *c) { return c ? (void *)c->stream : nullptr; }
+
+void strsim_split_offsets(uint64_t len, uint64_t n, uint64_t *out)
+{
+    // reference split_offsets, strsim.rs:21-39: len/n rows each, the remainder goes to the last part
+    if (n == 0 || !out) return;
+    if (n == 1) { out[0] = 0; out[1] = len; return; }
+    const uint64_t chunk = len / n;
+    for (uint64_t p = 0; p < n; ++p) {
+        out[2 * p] = p * chunk;
+        out[2 * p + 1] = (p == n - 1) ? len - p * chunk : chunk;
+    }
+}
+
+int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                        const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *out, uint64_t out_rows)
+{
+    if (!c) { set_error("strsim_pairs_device: ctx is NULL"); return STRSIM_ERR_ARG; }
+    if (measure < 0 || measure >= STRSIM_NUM_MEASURES) {
+        set_error("strsim_pairs_device: unknown measure %d", measure);
+        return STRSIM_ERR_ARG;
+    }
+    // shape rule of parallel_apply, strsim.rs:48-52
+    if (a_rows != b_rows && a_rows != 1 && b_rows != 1) {
+        set_error("Inputs must have the same length, or one of them must be a Utf8 literal.");
+        return STRSIM_ERR_SHAPE;
+    }
+    const uint64_t n = (a_rows == 1) ? b_rows : a_rows;
+    if (out_rows != n) {
+        set_error("strsim_pairs_device: out_rows=%llu but the inputs produce %llu rows", (unsigned long long)out_rows,
+                  (unsigned long long)n);
+        return STRSIM_ERR_ARG;
+    }
+    if (n == 0) return STRSIM_OK;
+    if (!a_off || !b_off || !out) { set_error("strsim_pairs_device: NULL buffer"); return STRSIM_ERR_ARG; }
+    int rc = ctx_set_device(c);
+    if (rc) return rc;
+    // the ring slot about to be reused must have been retired
+    const int slot = c->head;
+    if (c->slot_pending[slot]) {
+        rc = strsim_ctx_synchronize(c);
+        if (rc) return rc;
+    }
+    const uint64_t nchunks = (n + 63) >> 6;
+    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, nchunks * sizeof(unsigned long long));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->status + slot, 0, sizeof(DevStatus), c->stream));
+
+    LaunchArgs la;
+    la.offA = a_off; la.valA = a_val; la.rowsA = a_rows;
+    la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
+    la.out = out; la.n = n;
+    la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
+    la.lane_grid = c->num_cu * 5;  // 32 KiB LDS per wave-sized workgroup -> 5 resident per CU
+    la.wave_grid = c->num_cu * 8;
+    la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;
+    if (c->timing) {
+        for (int i = 0; i < 3; ++i)
+            if (!c->ev[slot][i]) HIP_TRY(hipEventCreate(&c->ev[slot][i]));
+        la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
+    }
+    hipError_t e = launch_pairs(measure, la);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    c->slot_timed[slot] = c->timing;
+    HIP_TRY(hipMemcpyAsync(c->status_host + slot, c->status + slot, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+    c->slot_pending[slot] = true;
+    c->head = (slot + 1) % strsim_ctx::RING;
+    return STRSIM_OK;
+}
+
+int strsim_ctx_synchronize(strsim_ctx_t *c)
+{
+    if (!c) { set_error("strsim_ctx_synchronize: ctx is NULL"); return STRSIM_ERR_ARG; }
+    int rc = ctx_set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ctx_drain(c);
+}
+
+int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                      const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *out, uint64_t out_rows)
+{
+    if (!c) { set_error("strsim_pairs_host: ctx is NULL"); return STRSIM_ERR_ARG; }
+    if (a_rows != b_rows && a_rows != 1 && b_rows != 1) {
+        set_error("Inputs must have the same length, or one of them must be a Utf8 literal.");
+        return STRSIM_ERR_SHAPE;
+    }
+    const uint64_t n = (a_rows == 1) ? b_rows : a_rows;
+    if (out_rows != n) { set_error("strsim_pairs_host: out_rows mismatch"); return STRSIM_ERR_ARG; }
+    if (n == 0) return STRSIM_OK;
+    if (!a_off || !b_off || !out) { set_error("strsim_pairs_host: NULL buffer"); return STRSIM_ERR_ARG; }
+    int rc = ctx_set_device(c);
+    if (rc) return rc;
+    const size_t abytes = a_off[a_rows], bbytes = b_off[b_rows];
+    const size_t need[5] = {(a_rows + 1) * 4, abytes + 1, (b_rows + 1) * 4, bbytes + 1, n * 8};
+    for (int i = 0; i < 5; ++i) {
+        rc = ctx_reserve(&c->stage[i], &c->stage_cap[i], need[i]);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->stage[0], a_off, (a_rows + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (abytes) HIP_TRY(hipMemcpyAsync(c->stage[1], a_val, abytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->stage[2], b_off, (b_rows + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (bbytes) HIP_TRY(hipMemcpyAsync(c->stage[3], b_val, bbytes, hipMemcpyHostToDevice, c->stream));
+    rc = strsim_pairs_device(c, measure, (const uint32_t *)c->stage[0], (const uint8_t *)c->stage[1], a_rows,
+                             (const uint32_t *)c->stage[2], (const uint8_t *)c->stage[3], b_rows, (double *)c->stage[4], n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->stage[4], n * 8, hipMemcpyDeviceToHost, c->stream));
+    return strsim_ctx_synchronize(c);
+}
+
+int strsim_ctx_timing_enable(strsim_ctx_t *c, int enable)
+{
+    if (!c) { set_error("strsim_ctx_timing_enable: ctx is NULL"); return STRSIM_ERR_ARG; }
+    int rc = strsim_ctx_synchronize(c);
+    if (rc) return rc;
+    c->timing = enable != 0;
+    return STRSIM_OK;
+}
+
+int strsim_ctx_timing_read(strsim_ctx_t *c, double *lane_ms, uint64_t *lane_launches, double *wave_ms,
+                           uint64_t *wave_launches)
+{
+    if (!c) { set_error("strsim_ctx_timing_read: ctx is NULL"); return STRSIM_ERR_ARG; }
+    int rc = strsim_ctx_synchronize(c);
+    if (rc) return rc;
+    if (lane_ms) *lane_ms = c->lane_ms;
+    if (lane_launches) *lane_launches = c->lane_launches;
+    if (wave_ms) *wave_ms = c->wave_ms;
+    if (wave_launches) *wave_launches = c->wave_launches;
+    c->lane_ms = c->wave_ms = 0;
+    c->lane_launches = c->wave_launches = 0;
+    return STRSIM_OK;
+}
+
+uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *c) { return c ? c->last_wave_rows : 0; }
+
+} // extern "C"

@@ -1,0 +1,30 @@
+// strsim_kernels.h -- launch interface between the C ABI (strsim_capi.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace strsim {
+
+constexpr int WAVE_CAP = 1024; // wave-per-pair kernels: max bytes (hence scalar values) per string
+
+struct DevStatus {
+    unsigned int wave_rows; // rows finished by k_wave_pairs
+    unsigned int huge_rows; // rows longer than WAVE_CAP (left for the long-string pass)
+    unsigned int max_len;   // longest such string, bytes
+    unsigned int pad[13];
+};
+
+struct LaunchArgs {
+    const uint32_t *offA; const uint8_t *valA; uint64_t rowsA;
+    const uint32_t *offB; const uint8_t *valB; uint64_t rowsB;
+    double *out; uint64_t n;
+    unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
+    DevStatus *status;            // zeroed by the caller
+    hipStream_t stream;
+    int lane_grid, wave_grid;     // max workgroups for the two kernels
+    hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)
+};
+
+hipError_t launch_pairs(int measure, const LaunchArgs &a);
+
+} // namespace strsim

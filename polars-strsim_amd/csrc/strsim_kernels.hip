@@ -1,0 +1,453 @@
+// strsim_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the five pairwise string-similarity
+// measures of polars-strsim (reference src/expressions/strsim.rs:109-345).
+//
+// Device data layout (per column shard): uint32 offsets[rows+1] + packed UTF-8 bytes; output f64[n].
+//
+// Two kernel families, both launched for every call:
+//
+//   k_lane_pairs<M>   ONE PAIR PER LANE.  A wave takes 64 consecutive rows; each lane pulls its two
+//                     strings (<= 32 bytes each, ASCII) into 2 x 8 VGPRs with unaligned 16-byte
+//                     loads (adjacent lanes read adjacent strings, so the wave's loads cover one
+//                     contiguous ~1 KiB span per column), builds the match table of b as an LDS
+//                     column peq[c][lane] (bank = lane: conflict-free), and runs the bit-parallel
+//                     cores of strsim_lane_core.h.  Rows that do not fit (longer than 32 bytes or
+//                     non-ASCII) are recorded in a 64-bit mask per 64-row chunk.
+//   k_wave_pairs<M>   ONE PAIR PER WAVE for the rows recorded in those masks: both strings are decoded
+//                     to Unicode scalar values in LDS (the reference works on `char`s,
+//                     strsim.rs:133,189,297) and processed with wave-wide anti-diagonal DP / ballot
+//                     matching.  Handles strings up to WAVE_CAP bytes.
+//
+// No MFMA anywhere: this is integer/byte work whose roofline is HBM bytes.
+// Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "strsim_lane_core.h"
+#include "strsim_kernels.h"
+
+namespace strsim {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// 32-byte window vals[off, off+32) into w[0..7]; bytes at or beyond `total` read as 0.
+__device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, uint32_t off, uint32_t total,
+                                              uint32_t (&w)[8])
+{
+    const uint8_t *p = vals + off;
+    if (total - off >= 32u) {
+        const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
+        const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
+        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+        w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+    } else {
+        const uint32_t avail = total - off; // < 32
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t v = 0u;
+            if (avail >= 4u * d + 4u) {
+                v = *reinterpret_cast<const u32_unaligned *>(p + 4 * d);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (avail > 4u * d + k) v |= (uint32_t)p[4 * d + k] << (8 * k);
+            }
+            w[d] = v;
+        }
+    }
+}
+
+struct LdsPeq {
+    const uint32_t *col; // &peq[lane]; entry for byte c at col[c * 64]
+    __device__ __forceinline__ uint32_t operator()(uint32_t c) const { return col[c * 64u]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int PEQ_SLOTS = 128;
+
+template <int MEASURE>
+__global__ __launch_bounds__(64) void k_lane_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
+                                                   uint64_t rowsA, const uint32_t *__restrict__ offB,
+                                                   const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                   double *__restrict__ out, uint64_t n,
+                                                   unsigned long long *__restrict__ slowmask)
+{
+    __shared__ uint32_t peq[PEQ_SLOTS * 64];
+    const uint32_t lane = lane_id();
+    for (int i = lane; i < PEQ_SLOTS * 64; i += 64) peq[i] = 0u;
+    __syncthreads();
+
+    const uint32_t totalA = offA[rowsA];
+    const uint32_t totalB = offB[rowsB];
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint64_t nchunks = (n + 63u) >> 6;
+    uint32_t *const col = &peq[lane];
+
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint64_t row = chunk * 64u + lane;
+        const bool valid = row < n;
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        if (valid) {
+            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+            a0 = offA[ra]; a1 = offA[ra + 1];
+            b0 = offB[rb]; b1 = offB[rb + 1];
+        }
+        const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
+        uint32_t wa[8], wb[8];
+        bool fast = valid && la8 <= 32u && lb8 <= 32u;
+        if (fast) {
+            load_window32(valA, a0, totalA, wa);
+            load_window32(valB, b0, totalB, wb);
+            // conservative ASCII test on the whole window (bytes past the string belong to its
+            // neighbours): a high bit anywhere sends the row to the code-point kernel
+            const uint32_t hi = (wa[0] | wa[1] | wa[2] | wa[3] | wa[4] | wa[5] | wa[6] | wa[7] |
+                                 wb[0] | wb[1] | wb[2] | wb[3] | wb[4] | wb[5] | wb[6] | wb[7]) & 0x80808080u;
+            fast = hi == 0u;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
+        }
+        const unsigned long long slow = __ballot(valid && !fast);
+        if (lane == 0) slowmask[chunk] = slow;
+
+        const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
+        const bool table = fast && lane_needs_table(la, lb);
+        const uint32_t lp = table ? lb : 0u; // pattern = b
+
+        // build the match table of b: one LDS atomic OR per pattern byte (in-order, no RMW latency chain)
+        {
+            uint32_t bit = table ? (1u << lane_peq_shift<MEASURE>(lb)) : 0u;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const bool on = (uint32_t)j < lp;
+                if (__ballot(on) == 0ull) break;
+                if (on) atomicOr(&col[lane_byte(wb, j) * 64u], bit);
+                bit <<= 1;
+            }
+        }
+
+        double r = 0.0;
+        if (fast) {
+            // lanes without a table (an empty side) take the early-outs inside lane_pair_result
+            r = lane_pair_result<MEASURE>(wa, la, wb, lb, LdsPeq{col});
+        }
+
+        // un-build: zero exactly the slots this pair touched
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const bool on = (uint32_t)j < lp;
+            if (__ballot(on) == 0ull) break;
+            if (on) col[lane_byte(wb, j) * 64u] = 0u;
+        }
+
+        if (fast) out[row] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_wave_pairs: one pair per wave, any UTF-8, strings up to WAVE_CAP bytes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt(uint32_t lane) { return (1ull << lane) - 1ull; }
+
+// `str::chars()` across a wave: lane i looks at byte i, lead bytes decode their scalar value and
+// compact it to dst[rank].  Valid UTF-8 only (the Rust &str / Arrow Utf8 contract).
+__device__ __forceinline__ uint32_t wave_decode(const uint8_t *__restrict__ p, uint32_t len8, uint32_t *dst,
+                                                bool &nonascii)
+{
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < len8; c0 += 64u) {
+        const uint32_t i = c0 + lane;
+        const bool in = i < len8;
+        const uint32_t b0 = in ? p[i] : 0x80u;
+        const bool lead = in && ((b0 & 0xC0u) != 0x80u);
+        const unsigned long long bal = __ballot(lead);
+        if (__ballot(in && b0 >= 0x80u) != 0ull) nonascii = true;
+        if (lead) {
+            uint32_t cp, need;
+            if (b0 < 0x80u) { cp = b0; need = 0; }
+            else if (b0 < 0xE0u) { cp = b0 & 0x1Fu; need = 1; }
+            else if (b0 < 0xF0u) { cp = b0 & 0x0Fu; need = 2; }
+            else { cp = b0 & 0x07u; need = 3; }
+            for (uint32_t k = 1; k <= need; ++k)
+                if (i + k < len8) cp = (cp << 6) | (p[i + k] & 0x3Fu);
+            dst[base + (uint32_t)__popcll(bal & lanemask_lt(lane))] = cp;
+        }
+        base += (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    return base;
+}
+
+// Levenshtein distance, anti-diagonal wavefront: lanes own 64 consecutive rows (chars of a) of a
+// strip, the strip sweeps over the columns (chars of b) with lane l one step behind lane l-1;
+// `up`/`diag` arrive from the lane below through a one-lane shift, lane 0 is fed from the previous
+// strip's bottom row kept in LDS (brow), lane 63 writes the new bottom row in place.
+__device__ __forceinline__ uint32_t wave_levenshtein(const uint32_t *sA, uint32_t la, const uint32_t *sB, uint32_t lb,
+                                                     uint32_t *brow)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t j = lane; j <= lb; j += 64u) brow[j] = j;
+    __syncthreads();
+    uint32_t result = 0;
+    for (uint32_t s0 = 0; s0 < la; s0 += 64u) {
+        const uint32_t nrows = (la - s0) < 64u ? (la - s0) : 64u;
+        const uint32_t r = s0 + lane + 1u;
+        const uint32_t pc = (r <= la) ? sA[r - 1u] : 0xFFFFFFFFu;
+        uint32_t cur = r;                      // D[r][0]
+        uint32_t upprev = s0, tcprev = 0u;     // lane 0's first diag is D[s0][0] = s0; other lanes get theirs by shift
+        uint32_t qb = 0u, qt = 0u;             // conveyors feeding lane 0: previous bottom row / text
+        const uint32_t nsteps = lb + nrows - 1u;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            const uint32_t k = t & 63u;
+            if (k == 0u) { // refill lane 0's feed for the next 64 steps
+                const uint32_t jb = t + 1u + lane, jt = t + lane;
+                qb = (jb <= lb) ? brow[jb] : 0u;
+                qt = (jt < lb) ? sB[jt] : 0xFFFFFFFEu;
+            }
+            uint32_t up = __shfl_up(cur, 1);
+            uint32_t tc = __shfl_up(tcprev, 1);
+            const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)qb, (int)k);
+            const uint32_t ft = (uint32_t)__builtin_amdgcn_readlane((int)qt, (int)k);
+            if (lane == 0u) {
+                up = fb;
+                tc = ft;
+            }
+            const uint32_t j = t + 1u - lane; // column (1-based); wraps for t+1 < lane
+            if (j - 1u < lb) {
+                const uint32_t sub = upprev + (pc != tc ? 1u : 0u);
+                uint32_t nv = up + 1u;
+                nv = nv < sub ? nv : sub;
+                const uint32_t lf = cur + 1u;
+                nv = nv < lf ? nv : lf;
+                cur = nv;
+                if (lane == 63u) brow[j] = nv;
+            }
+            upprev = up;
+            tcprev = tc;
+        }
+        __syncthreads();
+        if (s0 + 64u >= la) result = (uint32_t)__shfl((int)cur, (int)((la - 1u) & 63u));
+    }
+    return result;
+}
+
+// In-place compaction of the flagged entries of s[0..len) to the front; returns how many.
+__device__ __forceinline__ uint32_t wave_compact(uint32_t *s, const uint8_t *flag, uint32_t len)
+{
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+        const uint32_t i = c0 + lane;
+        const bool f = i < len && flag[i] != 0;
+        const uint32_t v = f ? s[i] : 0u;
+        const unsigned long long bal = __ballot(f);
+        __syncthreads();
+        if (f) s[base + (uint32_t)__popcll(bal & lanemask_lt(lane))] = v;
+        base += (uint32_t)__popcll(bal);
+        __syncthreads();
+    }
+    return base;
+}
+
+// Jaro matching on scalar values (strsim.rs:200-237): a is walked sequentially, the window of b is
+// scanned 64 positions at a time and the lowest hit wins (ballot + ctz).  Destroys sA/sB.
+__device__ __forceinline__ void wave_jaro(uint32_t *sA, uint32_t la, uint32_t *sB, uint32_t lb, uint8_t *fa, uint8_t *fb,
+                                          uint32_t &m_out, uint32_t &t_out)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t mx = la > lb ? la : lb;
+    const uint32_t half = mx >> 1;
+    const uint32_t bound = (half ? half : 1u) - 1u;
+    for (uint32_t i = lane; i < la; i += 64u) fa[i] = 0;
+    for (uint32_t j = lane; j < lb; j += 64u) fb[j] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    const uint32_t ni = la < lb + bound ? la : lb + bound; // `.take(b.len() + bound)` (:208)
+    for (uint32_t i = 0; i < ni; ++i) {
+        const uint32_t lo = i > bound ? i - bound : 0u;
+        const uint32_t hi = (i + bound) < (lb - 1u) ? (i + bound) : (lb - 1u);
+        if (lo > hi) continue;
+        const uint32_t ai = sA[i];
+        for (uint32_t cb = lo & ~63u; cb <= hi; cb += 64u) {
+            const uint32_t j = cb + lane;
+            const bool ok = j >= lo && j <= hi && sB[j] == ai && fb[j] == 0;
+            const unsigned long long bal = __ballot(ok);
+            if (bal != 0ull) {
+                const uint32_t jm = cb + (uint32_t)__builtin_ctzll(bal);
+                if (lane == 0u) { fb[jm] = 1; fa[i] = 1; }
+                ++m;
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    wave_compact(sA, fa, la);
+    wave_compact(sB, fb, lb);
+    uint32_t t = 0;
+    for (uint32_t k0 = 0; k0 < m; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        t += (uint32_t)__popcll(__ballot(k < m && sA[k] != sB[k]));
+    }
+    m_out = m;
+    t_out = t;
+}
+
+// Multiset intersection size.  ASCII: two 128-bin LDS histograms.  Otherwise rank counting: the
+// k-th occurrence (0-based) of a scalar value in a is matched iff k < its count in b.
+__device__ __forceinline__ uint32_t wave_multiset_isect(const uint32_t *sA, uint32_t la, const uint32_t *sB, uint32_t lb,
+                                                        uint32_t *hist /* >= 256 words */, bool nonascii)
+{
+    const uint32_t lane = lane_id();
+    uint32_t acc = 0;
+    if (!nonascii) {
+        for (uint32_t c = lane; c < 256u; c += 64u) hist[c] = 0u;
+        __syncthreads();
+        for (uint32_t i = lane; i < la; i += 64u) atomicAdd(&hist[sA[i]], 1u);
+        for (uint32_t j = lane; j < lb; j += 64u) atomicAdd(&hist[128u + sB[j]], 1u);
+        __syncthreads();
+        for (uint32_t c = lane; c < 128u; c += 64u) {
+            const uint32_t x = hist[c], y = hist[128u + c];
+            acc += x < y ? x : y;
+        }
+    } else {
+        for (uint32_t i0 = 0; i0 < la; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const bool in = i < la;
+            const uint32_t c = in ? sA[i] : 0u;
+            uint32_t k = 0, cb = 0;
+            const uint32_t lim = (i0 + 64u) < la ? (i0 + 64u) : la;
+            for (uint32_t i2 = 0; i2 < lim; ++i2) k += (sA[i2] == c && i2 < i) ? 1u : 0u;
+            for (uint32_t j = 0; j < lb; ++j) cb += (sB[j] == c) ? 1u : 0u;
+            acc += (in && k < cb) ? 1u : 0u;
+        }
+    }
+    return wave_sum(acc);
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
+                                                   uint64_t rowsA, const uint32_t *__restrict__ offB,
+                                                   const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                   double *__restrict__ out, uint64_t n,
+                                                   const unsigned long long *__restrict__ slowmask,
+                                                   DevStatus *__restrict__ status)
+{
+    __shared__ uint32_t sA[WAVE_CAP];
+    __shared__ uint32_t sB[WAVE_CAP];
+    __shared__ uint32_t aux[WAVE_CAP + 64];
+    const uint32_t lane = lane_id();
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint64_t nchunks = (n + 63u) >> 6;
+    uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
+
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        unsigned long long mask = slowmask[chunk];
+        mask = ((unsigned long long)uniform((uint32_t)(mask >> 32)) << 32) | uniform((uint32_t)mask);
+        while (mask != 0ull) {
+            const uint32_t bitpos = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const uint64_t row = chunk * 64u + bitpos;
+            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+            const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
+            const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
+            const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
+            ++my_rows;
+            if (la8 > (uint32_t)WAVE_CAP || lb8 > (uint32_t)WAVE_CAP) {
+                ++my_huge; // finished by the host-driven long-string pass (see strsim_capi.cpp)
+                const uint32_t ml = la8 > lb8 ? la8 : lb8;
+                my_maxlen = my_maxlen > ml ? my_maxlen : ml;
+                continue;
+            }
+            double r;
+            if (la8 == 0u && lb8 == 0u) {
+                r = 1.0;
+            } else if (la8 == 0u || lb8 == 0u) {
+                r = 0.0; // also Levenshtein: 1 - max/max
+            } else {
+                bool nonascii = false;
+                __syncthreads();
+                const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
+                const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
+                if (MEASURE == LEVENSHTEIN) {
+                    const uint32_t dist = wave_levenshtein(sA, la, sB, lb, aux);
+                    r = epilogue_levenshtein(dist, la, lb);
+                } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+                    uint32_t prefix = 0;
+                    if (MEASURE == JARO_WINKLER) {
+                        const uint32_t lim = la < lb ? (la < 4u ? la : 4u) : (lb < 4u ? lb : 4u);
+                        const unsigned long long ne = __ballot(lane < lim && sA[lane < lim ? lane : 0u] != sB[lane < lim ? lane : 0u]);
+                        prefix = ne ? (uint32_t)__builtin_ctzll(ne) : lim;
+                    }
+                    uint32_t m, t;
+                    uint8_t *fl = reinterpret_cast<uint8_t *>(aux);
+                    wave_jaro(sA, la, sB, lb, fl, fl + WAVE_CAP, m, t);
+                    r = epilogue_jaro(m, t, la, lb);
+                    if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, prefix);
+                } else {
+                    const uint32_t isect = wave_multiset_isect(sA, la, sB, lb, aux, nonascii);
+                    r = MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+                }
+            }
+            if (lane == 0u) out[row] = r;
+        }
+    }
+    if (lane == 0u && my_rows != 0u) {
+        atomicAdd(&status->wave_rows, my_rows);
+        if (my_huge != 0u) {
+            atomicAdd(&status->huge_rows, my_huge);
+            atomicMax(&status->max_len, my_maxlen);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int M>
+static void launch_pair(const LaunchArgs &a)
+{
+    const uint64_t nchunks = (a.n + 63u) >> 6;
+    const uint64_t g1 = nchunks < (uint64_t)a.lane_grid ? nchunks : (uint64_t)a.lane_grid;
+    const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
+    if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
+    hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, a.out, a.n, a.slowmask);
+    if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
+    hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status);
+    if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
+}
+
+hipError_t launch_pairs(int measure, const LaunchArgs &a)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (measure) {
+    case LEVENSHTEIN: launch_pair<LEVENSHTEIN>(a); break;
+    case JARO: launch_pair<JARO>(a); break;
+    case JARO_WINKLER: launch_pair<JARO_WINKLER>(a); break;
+    case JACCARD: launch_pair<JACCARD>(a); break;
+    case SORENSEN_DICE: launch_pair<SORENSEN_DICE>(a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace strsim

@@ -1,0 +1,87 @@
+"""ctypes binding of libpolars_strsim_amd.so (C ABI: include/strsim_amd.h).
+
+The library is built in-tree by polars-strsim_amd/Makefile into the drop-in package directory
+polars_strsim/ (where Polars looks for the plugin).  There is no Python or CPU fallback: if the
+library is missing this module raises.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "polars_strsim", "libpolars_strsim_amd.so")
+
+MEASURES = ("levenshtein", "jaro", "jaro_winkler", "jaccard", "sorensen_dice")  # strsim.rs:9-15
+MEASURE_ID = {m: i for i, m in enumerate(MEASURES)}
+
+STATUS = {0: "OK", 1: "ERR_SHAPE", 2: "ERR_ARG", 3: "ERR_NO_DEVICE", 4: "ERR_HIP", 5: "ERR_OOM", 6: "ERR_DTYPE",
+          7: "ERR_INTERNAL"}
+
+
+class StrsimError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{STATUS.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+class ShapeMismatch(StrsimError, ValueError):
+    """reference: PolarsError::ShapeMismatch, strsim.rs:48-52"""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` (hipcc, gfx950). "
+            "polars-strsim_amd has no Python/CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.strsim_abi_version.restype = C.c_uint32
+    L.strsim_abi_version.argtypes = []
+    L.strsim_last_error_message.restype = C.c_char_p
+    L.strsim_last_error_message.argtypes = []
+    L.strsim_device_count.restype = i32
+    L.strsim_device_count.argtypes = []
+    L.strsim_ctx_create.restype = i32
+    L.strsim_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.strsim_ctx_destroy.restype = None
+    L.strsim_ctx_destroy.argtypes = [vp]
+    L.strsim_ctx_stream.restype = vp
+    L.strsim_ctx_stream.argtypes = [vp]
+    for name in ("strsim_pairs_device", "strsim_pairs_host"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i32, vp, vp, u64, vp, vp, u64, vp, u64]
+    L.strsim_ctx_synchronize.restype = i32
+    L.strsim_ctx_synchronize.argtypes = [vp]
+    L.strsim_split_offsets.restype = None
+    L.strsim_split_offsets.argtypes = [u64, u64, vp]
+    L.strsim_ctx_timing_enable.restype = i32
+    L.strsim_ctx_timing_enable.argtypes = [vp, i32]
+    L.strsim_ctx_timing_read.restype = i32
+    L.strsim_ctx_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_double),
+                                         C.POINTER(u64)]
+    L.strsim_ctx_last_wave_rows.restype = u64
+    L.strsim_ctx_last_wave_rows.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().strsim_last_error_message().decode("utf-8", "replace")
+    if rc == 1:
+        raise ShapeMismatch(rc, msg)
+    raise StrsimError(rc, msg)
+
+
+def measure_id(measure):
+    if isinstance(measure, str):
+        return MEASURE_ID[measure]
+    return int(measure)

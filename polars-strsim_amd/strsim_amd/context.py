@@ -1,0 +1,115 @@
+"""Device context + the two compute entry points of the C ABI, for numpy (host) and torch (device) buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, measure_id
+
+
+def split_offsets(length, n):
+    """Row partition of the reference's split_offsets (strsim.rs:21-39) -> [(offset, len)] * n."""
+    out = np.zeros(2 * n, dtype=np.uint64)
+    lib().strsim_split_offsets(int(length), int(n), out.ctypes.data)
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+def device_count():
+    return int(lib().strsim_device_count())
+
+
+class Context:
+    """One GPU + one HIP stream + workspace (include/strsim_amd.h: strsim_ctx_t).  One per thread."""
+
+    def __init__(self, device=0, stream=None):
+        """`stream`: an int hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None for an own stream."""
+        self._h = C.c_void_p()
+        check(lib().strsim_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().strsim_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def stream(self):
+        return lib().strsim_ctx_stream(self._h)
+
+    def synchronize(self):
+        check(lib().strsim_ctx_synchronize(self._h))
+
+    def timing(self, enable=True):
+        check(lib().strsim_ctx_timing_enable(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        """-> dict(lane_ms, lane_launches, wave_ms, wave_launches) accumulated since the last read."""
+        a, b = C.c_double(), C.c_double()
+        na, nb = C.c_uint64(), C.c_uint64()
+        check(lib().strsim_ctx_timing_read(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return {"lane_ms": a.value, "lane_launches": na.value, "wave_ms": b.value, "wave_launches": nb.value}
+
+    @property
+    def last_wave_rows(self):
+        return int(lib().strsim_ctx_last_wave_rows(self._h))
+
+    # ---- device-resident (torch tensors on this context's GPU) -------------------------------------
+    def pairs_device(self, measure, a_offsets, a_values, b_offsets, b_values, out=None):
+        """Enqueue one pass; tensors are torch CUDA tensors (offsets int32/uint32 [rows+1], values uint8).
+        Returns the f64 output tensor; complete after synchronize()."""
+        import torch
+        ra, rb = a_offsets.numel() - 1, b_offsets.numel() - 1
+        n = rb if ra == 1 else ra
+        for t in (a_offsets, b_offsets):
+            assert t.is_cuda and t.element_size() == 4 and t.is_contiguous()
+        for t in (a_values, b_values):
+            assert t.is_cuda and t.element_size() == 1 and t.is_contiguous()
+        if out is None:
+            out = torch.empty(n if (ra == rb or ra == 1 or rb == 1) else 0, dtype=torch.float64, device=a_offsets.device)
+        check(lib().strsim_pairs_device(self._h, measure_id(measure),
+                                        a_offsets.data_ptr(), a_values.data_ptr(), ra,
+                                        b_offsets.data_ptr(), b_values.data_ptr(), rb,
+                                        out.data_ptr(), out.numel()))
+        return out
+
+    # ---- host-resident (numpy) ---------------------------------------------------------------------
+    def pairs_host(self, measure, a_offsets, a_values, b_offsets, b_values):
+        """Synchronous: numpy uint32 offsets + uint8 values in, numpy f64 out."""
+        ao = np.ascontiguousarray(a_offsets, dtype=np.uint32)
+        bo = np.ascontiguousarray(b_offsets, dtype=np.uint32)
+        av = np.ascontiguousarray(a_values, dtype=np.uint8)
+        bv = np.ascontiguousarray(b_values, dtype=np.uint8)
+        if av.size == 0:
+            av = np.zeros(1, dtype=np.uint8)
+        if bv.size == 0:
+            bv = np.zeros(1, dtype=np.uint8)
+        ra, rb = ao.size - 1, bo.size - 1
+        n = rb if ra == 1 else ra
+        if ra != rb and ra != 1 and rb != 1:
+            n = 0
+        out = np.empty(n, dtype=np.float64)
+        check(lib().strsim_pairs_host(self._h, measure_id(measure), ao.ctypes.data, av.ctypes.data, ra,
+                                      bo.ctypes.data, bv.ctypes.data, rb, out.ctypes.data, n))
+        return out
+
+
+def pack_strings(strings):
+    """list[str|bytes] -> (uint32 offsets[n+1], uint8 values): the device column layout."""
+    bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strings]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint32)
+    if bs:
+        offs[1:] = np.cumsum([len(x) for x in bs], dtype=np.uint64).astype(np.uint32)
+    vals = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return offs, vals

@@ -1,0 +1,144 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Bar: bit-exact f64 for all five measures (integer intermediates are exact; the epilogues use the
+reference's IEEE operation order with contraction off).  north_star allows 1 ulp for the Jaro family;
+we hold it to 0.
+"""
+import struct
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+from golden_data import reference_vectors, readme_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import strsim_amd
+    return strsim_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(S):
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def u64(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_exact(got, exp, A, B, what):
+    bad = np.nonzero(u64(got) != u64(exp))[0]
+    if bad.size:
+        i = int(bad[0])
+        raise AssertionError(f"{what}: {bad.size}/{len(exp)} rows differ; first row {i}: "
+                             f"a={A[i if len(A) > 1 else 0]!r} b={B[i if len(B) > 1 else 0]!r} got={got[i]!r} exp={exp[i]!r}")
+
+
+def gpu(S, ctx, m, A, B):
+    ao, av = S.pack_strings(A)
+    bo, bv = S.pack_strings(B)
+    return ctx.pairs_host(m, ao, av, bo, bv)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_reference_vectors(S, ctx, measure):
+    rows = [r for r in reference_vectors() if r[0] == measure]
+    A = [r[2] for r in rows]
+    B = [r[3] for r in rows]
+    exp = np.array([r[4] for r in rows])
+    got = gpu(S, ctx, measure, A, B)
+    assert np.all(np.abs(got - exp) < 1e-8)  # strsim.rs:350
+    assert_bit_exact(got, O.batch_strings(measure, A, B), A, B, measure)
+
+
+def test_readme_table(S):
+    rows = readme_table()
+    A = [r["name_a"] for r in rows]
+    B = [r["name_b"] for r in rows]
+    for m in O.MEASURES:
+        got = getattr(S, m)(A, B)
+        for r, g in zip(rows, got):
+            if r[m] is None:
+                assert np.isnan(g)
+            else:
+                assert abs(g - r[m]) < 5e-7
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("alphabet,lo,hi", [("ab", 0, 32), (gen.ASCII_LOWER, 0, 32), (gen.ASCII_LOWER, 1, 12),
+                                             ("".join(chr(c) for c in range(1, 128)), 0, 32)])
+def test_lane_path_random(S, ctx, measure, alphabet, lo, hi):
+    A, B = gen.pairs(hash((measure, alphabet, hi)) & 0xFFFF, 20000, alphabet, lo, hi, max_bytes=32)
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    assert ctx.last_wave_rows <= 64  # only rows whose 32-byte window crosses the end of the buffer
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_wave_path_unicode_and_long(S, ctx, measure):
+    A, B = gen.pairs(11, 3000, gen.MIXED, 0, 40)
+    A2, B2 = gen.pairs(12, 600, gen.ASCII_LOWER, 20, 300)
+    A3, B3 = gen.pairs(13, 200, gen.MIXED, 100, 250, max_bytes=1024)
+    A, B = A + A2 + A3, B + B2 + B3
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    assert ctx.last_wave_rows > 1000
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_length_class_boundaries(S, ctx, measure):
+    import random
+    rng = random.Random(5)
+    A, B = [], []
+    for la in (0, 1, 2, 3, 12, 13, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1023, 1024):
+        for lb in (0, 1, 2, 31, 32, 33, 64, 65, 128, 1024):
+            A.append("".join(rng.choice("abc") for _ in range(la)))
+            B.append("".join(rng.choice("abc") for _ in range(lb)))
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_row_counts(S, ctx, measure, n):
+    A, B = gen.pairs(n, n, gen.ASCII_LOWER, 0, 20)
+    got = gpu(S, ctx, measure, A, B)
+    assert got.shape == (n,)
+    assert_bit_exact(got, O.batch_strings(measure, A, B), A, B, measure)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_literal_broadcast(S, ctx, measure):
+    A, B = gen.pairs(3, 5000, gen.ASCII_LOWER, 0, 32)
+    for lit in ("phillips", "", "é", "x" * 40):
+        got = gpu(S, ctx, measure, A, [lit])
+        assert_bit_exact(got, O.batch_strings(measure, A, [lit], 4), A, [lit], measure + " col,lit")
+        got = gpu(S, ctx, measure, [lit], B)
+        assert_bit_exact(got, O.batch_strings(measure, [lit], B, 4), [lit], B, measure + " lit,col")
+
+
+def test_shape_mismatch(S, ctx):
+    with pytest.raises(S.ShapeMismatch, match="Inputs must have the same length, or one of them must be a Utf8 literal."):
+        gpu(S, ctx, "jaro", ["a", "b"], ["a", "b", "c"])
+
+
+def test_nulls_propagate(S):
+    out = S.levenshtein(["phillips", None, "x"], ["philips", "a", None])
+    assert out[0] == 0.875 and np.isnan(out[1]) and np.isnan(out[2])
+
+
+def test_anchor_bits(S):
+    bits = lambda x: struct.unpack("<Q", struct.pack("<d", float(x)))[0]
+    a, b = ["phillips"], ["philips"]
+    assert bits(S.levenshtein(a, b)[0]) == 0x3FEC000000000000
+    assert bits(S.jaro(a, b)[0]) == 0x3FEEAAAAAAAAAAAB
+    assert bits(S.jaro_winkler(a, b)[0]) == 0x3FEF333333333333
+    assert bits(S.jaccard(a, b)[0]) == 0x3FEC000000000000
+    assert bits(S.sorensen_dice(a, b)[0]) == 0x3FEDDDDDDDDDDDDE

@@ -1,0 +1,95 @@
+"""Host-side check of the per-lane bit-parallel cores (strsim_lane_core.h) against the oracle.
+
+The same header is compiled into the gfx950 lane-per-pair kernels; here it is built with g++ and
+driven pair by pair, so algorithmic errors surface without a GPU.  Bit-exact comparison.
+"""
+import ctypes as C
+import os
+import random
+import struct
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+from golden_data import reference_vectors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDIR = os.path.join(ROOT, "tests", "cpu_harness")
+CSRC = os.path.join(ROOT, "polars-strsim_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    so = os.path.join(HDIR, "liblane_core_harness.so")
+    srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+                               "-I", CSRC, "-o", so, srcs[0]])
+    L = C.CDLL(so)
+    L.harness_lane_pair.restype = C.c_double
+    L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    return L
+
+
+def bits(x):
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def lane(L, m, a, b):
+    a = a.encode() if isinstance(a, str) else a
+    b = b.encode() if isinstance(b, str) else b
+    return L.harness_lane_pair(O.MEASURE_ID[m], a, len(a), b, len(b))
+
+
+def test_lane_core_on_reference_vectors(harness):
+    for m, fn, a, b, exp in reference_vectors():
+        got = lane(harness, m, a, b)
+        assert abs(got - exp) < 1e-8, (fn, a, b, got, exp)
+        assert bits(got) == bits(O.pair(m, a, b)), (fn, a, b)
+
+
+def _rand_pairs(rng, n, alphabet, maxlen=32):
+    out = []
+    for _ in range(n):
+        la = rng.randint(0, maxlen)
+        a = bytes(rng.choice(alphabet) for _ in range(la))
+        r = rng.random()
+        if r < 0.1:
+            b = a
+        elif r < 0.6:
+            b = bytearray(a)
+            for _ in range(rng.randint(1, 3)):
+                op = rng.randint(0, 2)
+                if op == 0 and len(b) < maxlen:
+                    b.insert(rng.randint(0, len(b)), rng.choice(alphabet))
+                elif op == 1 and len(b) > 0:
+                    del b[rng.randrange(len(b))]
+                elif len(b) > 0:
+                    b[rng.randrange(len(b))] = rng.choice(alphabet)
+            b = bytes(b)
+        else:
+            b = bytes(rng.choice(alphabet) for _ in range(rng.randint(0, maxlen)))
+        out.append((a, b))
+    return out
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("alphabet", [b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))])
+def test_lane_core_random_bit_exact(harness, measure, alphabet):
+    rng = random.Random(hash((measure, len(alphabet))) & 0xFFFF)
+    for a, b in _rand_pairs(rng, 3000, alphabet):
+        got = lane(harness, measure, a, b)
+        exp = O.pair(measure, a, b)
+        assert bits(got) == bits(exp), (measure, a, b, got, exp)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_lane_core_length_boundaries(harness, measure):
+    rng = random.Random(7)
+    for la in (0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 32):
+        for lb in (0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 32):
+            for _ in range(20):
+                a = bytes(rng.choice(b"abc") for _ in range(la))
+                b = bytes(rng.choice(b"abc") for _ in range(lb))
+                assert bits(lane(harness, measure, a, b)) == bits(O.pair(measure, a, b)), (a, b)
