@@ -8,10 +8,10 @@
 //   k_lane_pairs<M>   ONE PAIR PER LANE.  A wave takes 64 consecutive rows; each lane pulls its two
 //                     strings (<= 32 bytes each, ASCII) into 2 x 8 VGPRs with unaligned 16-byte
 //                     loads (adjacent lanes read adjacent strings, so the wave's loads cover one
-//                     contiguous ~1 KiB span per column), builds the match table of b as an LDS
-//                     column peq[c][lane] (bank = lane: conflict-free), and runs the bit-parallel
-//                     cores of strsim_lane_core.h.  Rows that do not fit (longer than 32 bytes or
-//                     non-ASCII) are recorded in a 64-bit mask per 64-row chunk.
+//                     contiguous ~1 KiB span per column), transposes b into bit-planes and runs the
+//                     bit-parallel cores of strsim_lane_core.h entirely in registers -- no LDS, so
+//                     occupancy is bounded by VGPRs only.  Rows that do not fit (longer than 32 bytes
+//                     or non-ASCII) are recorded in a 64-bit mask per 64-row chunk.
 //   k_wave_pairs<M>   ONE PAIR PER WAVE for the rows recorded in those masks: both strings are decoded
 //                     to Unicode scalar values in LDS (the reference works on `char`s,
 //                     strsim.rs:133,189,297) and processed with wave-wide anti-diagonal DP / ballot
@@ -64,35 +64,38 @@ __device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, 
     }
 }
 
-struct LdsPeq {
-    const uint32_t *col; // &peq[lane]; entry for byte c at col[c * 64]
-    __device__ __forceinline__ uint32_t operator()(uint32_t c) const { return col[c * 64u]; }
-};
+// ------------------------------------------------------------------------------------------------
+// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes, everything in registers (no LDS).
+// ------------------------------------------------------------------------------------------------
+constexpr int LANE_BLOCK = 256; // 4 independent waves per workgroup
 
-// ------------------------------------------------------------------------------------------------
-// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes.
-// ------------------------------------------------------------------------------------------------
-constexpr int PEQ_SLOTS = 128;
+// 4 * ceil(max over the wave of v / 4), at least 4 (v <= 32): three ballots, result in an SGPR
+__device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
+{
+    uint32_t g = 0;
+    if (__ballot(v > 16u) != 0ull) g = 4;
+    if (__ballot(v > 4u * (g + 2u)) != 0ull) g += 2;
+    if (__ballot(v > 4u * (g + 1u)) != 0ull) g += 1;
+    return 4u * (g + 1u);
+}
 
 template <int MEASURE>
-__global__ __launch_bounds__(64) void k_lane_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
-                                                   uint64_t rowsA, const uint32_t *__restrict__ offB,
-                                                   const uint8_t *__restrict__ valB, uint64_t rowsB,
-                                                   double *__restrict__ out, uint64_t n,
-                                                   unsigned long long *__restrict__ slowmask)
+__global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__restrict__ offA,
+                                                           const uint8_t *__restrict__ valA, uint64_t rowsA,
+                                                           const uint32_t *__restrict__ offB,
+                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                           double *__restrict__ out, uint64_t n,
+                                                           unsigned long long *__restrict__ slowmask)
 {
-    __shared__ uint32_t peq[PEQ_SLOTS * 64];
     const uint32_t lane = lane_id();
-    for (int i = lane; i < PEQ_SLOTS * 64; i += 64) peq[i] = 0u;
-    __syncthreads();
-
     const uint32_t totalA = offA[rowsA];
     const uint32_t totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
-    uint32_t *const col = &peq[lane];
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (LANE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (LANE_BLOCK / 64);
 
-    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint64_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
         const uint64_t row = chunk * 64u + lane;
         const bool valid = row < n;
         uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
@@ -103,52 +106,32 @@ __global__ __launch_bounds__(64) void k_lane_pairs(const uint32_t *__restrict__ 
         }
         const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
         uint32_t wa[8], wb[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
         bool fast = valid && la8 <= 32u && lb8 <= 32u;
+        uint32_t vary = 0u;
         if (fast) {
             load_window32(valA, a0, totalA, wa);
             load_window32(valB, b0, totalB, wb);
-            // conservative ASCII test on the whole window (bytes past the string belong to its
-            // neighbours): a high bit anywhere sends the row to the code-point kernel
-            const uint32_t hi = (wa[0] | wa[1] | wa[2] | wa[3] | wa[4] | wa[5] | wa[6] | wa[7] |
-                                 wb[0] | wb[1] | wb[2] | wb[3] | wb[4] | wb[5] | wb[6] | wb[7]) & 0x80808080u;
-            fast = hi == 0u;
-        } else {
-#pragma unroll
-            for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
+            // conservative tests on the whole 32-byte windows (bytes past a string belong to its
+            // neighbours): any high bit sends the row to the code-point kernel; the varying low bits
+            // decide how many bit-planes the match masks need
+            uint32_t any;
+            vary = window_vary(wa, wb, any);
+            fast = (any & 0x80u) == 0u;
         }
         const unsigned long long slow = __ballot(valid && !fast);
         if (lane == 0) slowmask[chunk] = slow;
+        if (__ballot(fast) == 0ull) continue;
 
         const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
-        const bool table = fast && lane_needs_table(la, lb);
-        const uint32_t lp = table ? lb : 0u; // pattern = b
-
-        // build the match table of b: one LDS atomic OR per pattern byte (in-order, no RMW latency chain)
-        {
-            uint32_t bit = table ? (1u << lane_peq_shift<MEASURE>(lb)) : 0u;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const bool on = (uint32_t)j < lp;
-                if (__ballot(on) == 0ull) break;
-                if (on) atomicOr(&col[lane_byte(wb, j) * 64u], bit);
-                bit <<= 1;
-            }
-        }
-
-        double r = 0.0;
-        if (fast) {
-            // lanes without a table (an empty side) take the early-outs inside lane_pair_result
-            r = lane_pair_result<MEASURE>(wa, la, wb, lb, LdsPeq{col});
-        }
-
-        // un-build: zero exactly the slots this pair touched
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const bool on = (uint32_t)j < lp;
-            if (__ballot(on) == 0ull) break;
-            if (on) col[lane_byte(wb, j) * 64u] = 0u;
-        }
-
+        const uint32_t tmax = wave_max_round4(la);
+        const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
+        const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
+        double r;
+        if (need7) r = lane_pair_result<MEASURE, 7>(wa, la, wb, lb, tmax);
+        else if (need6) r = lane_pair_result<MEASURE, 6>(wa, la, wb, lb, tmax);
+        else r = lane_pair_result<MEASURE, 5>(wa, la, wb, lb, tmax);
         if (fast) out[row] = r;
     }
 }
@@ -425,10 +408,11 @@ template <int M>
 static void launch_pair(const LaunchArgs &a)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
-    const uint64_t g1 = nchunks < (uint64_t)a.lane_grid ? nchunks : (uint64_t)a.lane_grid;
+    const uint64_t nblk = (nchunks + (LANE_BLOCK / 64) - 1) / (LANE_BLOCK / 64);
+    const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
     const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
-    hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+    hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,

@@ -2,11 +2,11 @@
 // <= 32 ASCII bytes.  Host/device portable so the exact arithmetic the gfx950 kernels run can also be
 // exercised by a CPU harness in tests/ (there is no GPU in the build container).
 //
-// Every routine sees one pair:
-//   * the "pattern" string P (<= 32 bytes) has already been turned into a match table
-//     peq(c) = bitmask of the positions of byte c in P   (an LDS column per lane on the GPU);
-//   * the "text" string T sits in eight 32-bit registers wt[0..7] (little-endian bytes, bytes at or
-//     beyond lt are don't-care).
+// Every routine sees one pair, both strings in eight 32-bit registers each (little-endian bytes,
+// bytes at or beyond the length are don't-care):
+//   * the "pattern" string (b) is transposed into bit-planes, from which the match mask of any byte
+//     is two VALU ops per plane (eq_mask) -- no lookup table, no LDS;
+//   * the "text" string (a) is walked byte by byte.
 //
 // Semantics restated (reference = /root/reference/src/expressions/strsim.rs):
 //   lev_myers32      -> integer edit distance of Levenshtein::compute      (:141-160)
@@ -40,61 +40,191 @@ STRSIM_HD uint32_t popc32(uint32_t x)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Bit-sliced match masks.  The "pattern" string (<= 32 bytes, in eight registers) is transposed once
+// into bit-planes: bit i of plane k = bit k of pattern byte i.  The positions where the pattern equals a
+// byte c are then   Eq(c) = valid & AND_k ~(P_k ^ m_k),  m_k = bit k of c replicated to all 32 bits
+// -- two VALU ops per plane (v_bfe_i32 + v_bitop3_b32) and no memory at all, so the lane-per-pair
+// kernels need no LDS and run at full occupancy.  Only the low NP bits of the bytes are compared:
+// the caller guarantees that bits >= NP are the same in every byte of the pair (a-z: NP = 5).
+// ---------------------------------------------------------------------------------------------
+STRSIM_HD uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+    // v_perm_b32: result byte n = byte sel[n] of the 8 bytes {s0 = bytes 4..7, s1 = bytes 0..3}
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t sl = (sel >> (8 * n)) & 0xFFu;
+        const uint32_t b = sl < 8u ? (uint32_t)((src >> (8 * sl)) & 0xFFu) : (sl >= 0x0Du ? 0xFFu : 0u);
+        r |= b << (8 * n);
+    }
+    return r;
+#endif
+}
+
+// bit `off` of w replicated to all 32 bits (0 or ~0)
+STRSIM_HD uint32_t bit_fill(uint32_t w, int off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_sbfe((int)w, (unsigned)off, 1u);
+#else
+    return 0u - ((w >> off) & 1u);
+#endif
+}
+
+// 8x8 bit-matrix transpose of the eight bytes {lo, hi}: afterwards byte k holds bit k of the eight
+// source bytes (bit i of byte k = bit k of source byte i).  Three block-swap rounds (1, 2, 4 bits).
+STRSIM_HD void transpose8x8(uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00AA00AAu; lo = lo ^ t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00AA00AAu; hi = hi ^ t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
+    t = (lo ^ (hi << 4)) & 0xF0F0F0F0u;
+    lo ^= t;
+    hi ^= t >> 4;
+}
+
+// Planes 0..NP-1 of the 32 pattern bytes w[0..7] (NP in 1..8).
+template <int NP>
+STRSIM_HD void build_planes(const uint32_t (&w)[8], uint32_t (&P)[NP])
+{
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        lo[g] = w[2 * g];
+        hi[g] = w[2 * g + 1];
+        transpose8x8(lo[g], hi[g]);
+    }
+    // 4x4 byte transposes: plane k = byte k of group 0..3 (planes 0-3 from lo[], 4-7 from hi[])
+    {
+        const uint32_t u0 = perm_b32(lo[1], lo[0], 0x05010400u); // [lo0.b0, lo1.b0, lo0.b1, lo1.b1]
+        const uint32_t u2 = perm_b32(lo[3], lo[2], 0x05010400u);
+        P[0] = perm_b32(u2, u0, 0x05040100u);
+        if (NP > 1) P[1 < NP ? 1 : 0] = perm_b32(u2, u0, 0x07060302u);
+        if (NP > 2) {
+            const uint32_t u1 = perm_b32(lo[1], lo[0], 0x07030602u); // [lo0.b2, lo1.b2, lo0.b3, lo1.b3]
+            const uint32_t u3 = perm_b32(lo[3], lo[2], 0x07030602u);
+            P[2 < NP ? 2 : 0] = perm_b32(u3, u1, 0x05040100u);
+            if (NP > 3) P[3 < NP ? 3 : 0] = perm_b32(u3, u1, 0x07060302u);
+        }
+    }
+    if (NP > 4) {
+        const uint32_t u0 = perm_b32(hi[1], hi[0], 0x05010400u);
+        const uint32_t u2 = perm_b32(hi[3], hi[2], 0x05010400u);
+        P[4 < NP ? 4 : 0] = perm_b32(u2, u0, 0x05040100u);
+        if (NP > 5) P[5 < NP ? 5 : 0] = perm_b32(u2, u0, 0x07060302u);
+        if (NP > 6) {
+            const uint32_t u1 = perm_b32(hi[1], hi[0], 0x07030602u);
+            const uint32_t u3 = perm_b32(hi[3], hi[2], 0x07030602u);
+            P[6 < NP ? 6 : 0] = perm_b32(u3, u1, 0x05040100u);
+            if (NP > 7) P[7 < NP ? 7 : 0] = perm_b32(u3, u1, 0x07060302u);
+        }
+    }
+}
+
+// Positions (within `valid`) where the pattern equals byte `byte` (0..3, static) of dword w.
+template <int NP>
+STRSIM_HD uint32_t eq_mask(const uint32_t (&P)[NP], uint32_t valid, uint32_t w, int byte)
+{
+    uint32_t acc = valid;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) acc &= ~(P[k] ^ bit_fill(w, 8 * byte + k));
+    return acc;
+}
+
+// Smallest NP in {5,6,7} that separates every byte of the pair: `vary` = OR of (byte ^ byte') over the
+// pair's bytes folded to 8 bits.  (Bit 7 set = non-ASCII = not a lane-path row at all.)
+STRSIM_HD int planes_needed(uint32_t vary) { return (vary & 0x40u) ? 7 : ((vary & 0x20u) ? 6 : 5); }
+
+// Varying bits of the 64 bytes of two windows, folded to the low 8 bits; `any` gets the OR of all bytes.
+STRSIM_HD uint32_t window_vary(const uint32_t (&wa)[8], const uint32_t (&wb)[8], uint32_t &any)
+{
+    uint32_t o = wa[0], n = wa[0];
+#pragma unroll
+    for (int d = 1; d < 8; ++d) { o |= wa[d]; n &= wa[d]; }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { o |= wb[d]; n &= wb[d]; }
+    // fold the four byte lanes: OR of ORs, AND of ANDs
+    uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
+    uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
+    any = o8 & 0xFFu;
+    return (o8 ^ n8) & 0xFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Levenshtein distance, Myers/Hyyro bit-vector recurrence on one 32-bit word.
 // The pattern (length lp, 1..32) is LEFT-aligned: position j of P is bit j + (32 - lp), so the row
 // whose score we track is always bit 31.  The 32 - lp low bits act as rows of a fictitious prefix
 // that both strings share and that has already been consumed: their vertical deltas are -1
 // (Mv ones), the real rows start at +1 (Pv ones), and the bottom-row score starts at lp.
-// `peq(c)` must return the left-aligned mask.  lt >= 1.
+// No step is predicated: every lane runs the same `nit` columns (the text's bytes past lt are
+// don't-care) while the bottom-row deltas of each column are shifted into two history words; the score
+// after exactly lt columns is lp + popc(+1 history) - popc(-1 history) over the first lt columns.
+// `P` must already be shifted left by 32 - lp.  lt >= 1.  tmax: lane-uniform bound >= lt.
 // ---------------------------------------------------------------------------------------------
-template <class Peq>
-STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t lp, const Peq &peq)
+template <int NP>
+STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tmax, const uint32_t (&P)[NP], uint32_t lp)
 {
     const uint32_t s = 32u - lp;
-    uint32_t Pv = 0xFFFFFFFFu << s; // s <= 31 because lp >= 1
+    const uint32_t valid = 0xFFFFFFFFu << s; // s <= 31 because lp >= 1
+    uint32_t Pv = valid;
     uint32_t Mv = ~Pv;
-    uint32_t score = lp;
+    uint32_t hp = 0u, hn = 0u;
+    uint32_t nit = 0u;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        if ((uint32_t)j < lt) {
-            const uint32_t Eq = peq(lane_byte(wt, j));
+    for (int g = 0; g < 8; ++g) {
+        if ((uint32_t)(4 * g) >= tmax) break;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t Eq = eq_mask<NP>(P, valid, wt[g], jj);
             const uint32_t D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
             const uint32_t HP = Mv | ~(D0 | Pv);
             const uint32_t HN = Pv & D0;
-            score += HP >> 31;
-            score -= HN >> 31;
+            hp = (hp << 1) | (HP >> 31);
+            hn = (hn << 1) | (HN >> 31);
             const uint32_t X = (HP << 1) | 1u;
             Pv = (HN << 1) | ~(D0 | X);
             Mv = D0 & X;
         }
+        nit += 4u;
     }
-    return score;
+    // column j sits at history bit nit-1-j; keep columns 0..lt-1
+    const uint32_t cols = low_ones(lt) << (nit - lt);
+    return lp + popc32(hp & cols) - popc32(hn & cols);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Jaro matching (strsim.rs:200-237).  Pattern = b (peq gives positions in b, bit j = b[j]), text =
-// a.  Iterates a in order; for each a_i takes the LOWEST unflagged equal position of b inside
+// Jaro matching (strsim.rs:200-237).  Pattern = b (planes of b, bit j = b[j]), text = a.
+// Iterates a in order; for each a_i takes the LOWEST unflagged equal position of b inside
 // [i-bound, min(i+bound, lb-1)] -- the reference's inner `for j in lower..=upper { .. break }`.
 // Transpositions: the k-th flagged char of a vs the k-th flagged char of b (ascending positions);
-// they are equal iff bit j_k of peq(a_{i_k}) is set, so no byte of b is ever extracted.
+// they are equal iff bit j_k of Eq(a_{i_k}) is set, so no byte of b is ever extracted.
 // la, lb >= 1.  Returns m (matches) and t (unequal zipped pairs, NOT halved).
 // ---------------------------------------------------------------------------------------------
-template <class Peq>
-STRSIM_HD void jaro_match32(const uint32_t (&wa)[8], uint32_t la, uint32_t lb, const Peq &peq, uint32_t &m_out,
-                            uint32_t &t_out)
+template <int NP>
+STRSIM_HD void jaro_match32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmax, uint32_t lb, const uint32_t (&P)[NP],
+                            uint32_t &m_out, uint32_t &t_out)
 {
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u; // mx/2 - 1 (:200); mx == 1 only for the 1x1 case, window {i}
     const uint32_t lbmask = low_ones(lb);
+    const uint32_t live = low_ones(la);                                 // bit i set while i < la
     uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb); // ones at [0, min(i+bound, lb-1)]
     uint32_t lomask = 0u;                                              // ones below max(0, i-bound)
     uint32_t fb = 0u, fa = 0u;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if ((uint32_t)i < la) {
-            const uint32_t Eq = peq(lane_byte(wa, i));
-            const uint32_t cand = Eq & himask & ~(lomask | fb);
+    for (int g = 0; g < 8; ++g) {
+        if ((uint32_t)(4 * g) >= tmax) break;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * g + ii;
+            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[g], ii);
+            const uint32_t cand = Eq & himask & ~(lomask | fb) & bit_fill(live, i);
             const uint32_t bit = cand & (0u - cand);
             fb |= bit;
             fa |= (bit ? 1u : 0u) << i;
@@ -105,11 +235,16 @@ STRSIM_HD void jaro_match32(const uint32_t (&wa)[8], uint32_t la, uint32_t lb, c
     uint32_t t = 0u;
     uint32_t rest = fb;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if ((uint32_t)i < la && ((fa >> i) & 1u)) {
-            const uint32_t jbit = rest & (0u - rest);
+    for (int g = 0; g < 8; ++g) {
+        if ((uint32_t)(4 * g) >= tmax) break;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * g + ii;
+            const uint32_t on = bit_fill(fa, i);               // a_i was matched
+            const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
             rest ^= jbit;
-            if ((peq(lane_byte(wa, i)) & jbit) == 0u) ++t;
+            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[g], ii);
+            t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
         }
     }
     m_out = popc32(fb);
@@ -135,14 +270,19 @@ STRSIM_HD uint32_t common_prefix4(uint32_t a0, uint32_t la, uint32_t b0, uint32_
 // Any maximal matching of equal characters has exactly I edges: walk a, give each a_i the lowest
 // still-unused equal position of b.
 // ---------------------------------------------------------------------------------------------
-template <class Peq>
-STRSIM_HD uint32_t multiset_isect32(const uint32_t (&wa)[8], uint32_t la, const Peq &peq)
+template <int NP>
+STRSIM_HD uint32_t multiset_isect32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmax, uint32_t lb,
+                                    const uint32_t (&P)[NP])
 {
+    const uint32_t lbmask = low_ones(lb);
+    const uint32_t live = low_ones(la);
     uint32_t used = 0u;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if ((uint32_t)i < la) {
-            const uint32_t cand = peq(lane_byte(wa, i)) & ~used;
+    for (int g = 0; g < 8; ++g) {
+        if ((uint32_t)(4 * g) >= tmax) break;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t cand = eq_mask<NP>(P, lbmask, wa[g], ii) & ~used & bit_fill(live, 4 * g + ii);
             used |= cand & (0u - cand);
         }
     }
@@ -190,38 +330,37 @@ STRSIM_HD double epilogue_sorensen_dice(uint64_t isect, uint64_t la, uint64_t lb
 }
 
 // ---------------------------------------------------------------------------------------------
-// One lane's result for one pair, given the match table of b (left-aligned for Levenshtein, see
-// lane_peq_shift).  Handles the reference's early-outs (:128-130, :182-186, :288-292, :324-328); the
-// `a == b` early-out needs no code: every formula below yields exactly 1.0 for equal strings.
+// One lane's result for one pair (both strings <= 32 ASCII bytes, in registers).  Handles the
+// reference's early-outs (:128-130, :182-186, :288-292, :324-328); the `a == b` early-out needs no
+// code: every formula below yields exactly 1.0 for equal strings.
+// NP: number of low bits that tell the pair's bytes apart (planes_needed); tmax: uniform bound >= la.
 // ---------------------------------------------------------------------------------------------
-template <int MEASURE>
-STRSIM_HD uint32_t lane_peq_shift(uint32_t lb)
-{
-    return MEASURE == LEVENSHTEIN ? 32u - lb : 0u; // only used when lb >= 1
-}
-
-// true when the pair needs the match table / bit-parallel loops at all
-STRSIM_HD bool lane_needs_table(uint32_t la, uint32_t lb) { return la != 0u && lb != 0u; }
-
-template <int MEASURE, class Peq>
+template <int MEASURE, int NP>
 STRSIM_HD double lane_pair_result(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
-                                  const Peq &peq)
+                                  uint32_t tmax)
 {
-    if (la == 0u && lb == 0u) return 1.0;
-    if (la == 0u || lb == 0u) return 0.0; // Levenshtein: 1 - max/max = 0.0 as well (:160)
+    uint32_t P[NP];
+    build_planes<NP>(wb, P); // pattern = b
+    const bool live = la != 0u && lb != 0u;
+    const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u; // keep every shift amount in range on dead lanes
+    double r;
     if (MEASURE == LEVENSHTEIN) {
-        const uint32_t dist = lev_myers32(wa, la, lb, peq);
-        return epilogue_levenshtein(dist, la, lb);
+        const uint32_t s = 32u - lb1;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) P[k] <<= s;
+        const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
+        r = epilogue_levenshtein(dist, la1, lb1);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
-        jaro_match32(wa, la, lb, peq, m, t);
-        const double j = epilogue_jaro(m, t, la, lb);
-        if (MEASURE == JARO) return j;
-        return epilogue_jaro_winkler(j, common_prefix4(wa[0], la, wb[0], lb));
+        jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
+        r = epilogue_jaro(m, t, la1, lb1);
+        if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, common_prefix4(wa[0], la1, wb[0], lb1));
     } else {
-        const uint32_t isect = multiset_isect32(wa, la, peq);
-        return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+        const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
+        r = MEASURE == JACCARD ? epilogue_jaccard(isect, la1, lb1) : epilogue_sorensen_dice(isect, la1, lb1);
     }
+    if (!live) r = (la == 0u && lb == 0u) ? 1.0 : 0.0; // Levenshtein with one empty side: 1 - max/max = 0.0 (:160)
+    return r;
 }
 
 } // namespace strsim

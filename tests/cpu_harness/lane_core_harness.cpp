@@ -1,42 +1,69 @@
 // CPU harness for polars-strsim_amd/csrc/strsim_lane_core.h: runs the exact per-lane arithmetic of
-// the gfx950 lane-per-pair kernels on the host (match table in a plain array instead of an LDS
-// column) so tests/ can compare it with the oracle without a GPU.  Test infrastructure only.
+// the gfx950 lane-per-pair kernels on the host so tests/ can compare it with the oracle without a
+// GPU.  Test infrastructure only.
 #include <cstdint>
 #include <cstring>
 #include "strsim_lane_core.h"
 
 using namespace strsim;
 
-struct ArrayPeq {
-    const uint32_t *tab;
-    uint32_t operator()(uint32_t c) const { return tab[c & 127u]; }
-};
-
-template <int M>
-static double run(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb)
+template <int M, int NP>
+static double run_np(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb)
 {
-    uint32_t wa[8] = {0}, wb[8] = {0};
-    // garbage beyond the length, like the kernel's unmasked 32-byte window
-    std::memset(wa, 0x5a, sizeof wa);
-    std::memset(wb, 0x33, sizeof wb);
-    std::memcpy(wa, a, la);
-    std::memcpy(wb, b, lb);
-    uint32_t tab[128] = {0};
-    if (lane_needs_table(la, lb)) {
-        const uint32_t s = lane_peq_shift<M>(lb);
-        for (uint32_t j = 0; j < lb; ++j) tab[lane_byte(wb, (int)j)] |= (1u << j) << s;
-    }
-    ArrayPeq peq{tab};
-    return lane_pair_result<M>(wa, la, wb, lb, peq);
+    const uint32_t tmax = (la + 3u) & ~3u;
+    return lane_pair_result<M, NP>(wa, la, wb, lb, tmax ? tmax : 4u);
 }
 
-extern "C" double harness_lane_pair(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb)
+// force_np: 0 = choose like the kernel does (from the windows' varying bits), else 5/6/7/8
+template <int M>
+static double run(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
+{
+    uint32_t wa[8], wb[8];
+    // bytes past the length: what a neighbouring string could hold (the kernel loads a 32-byte window)
+    std::memset(wa, fill, sizeof wa);
+    std::memset(wb, fill, sizeof wb);
+    std::memcpy(wa, a, la);
+    std::memcpy(wb, b, lb);
+    uint32_t any;
+    const uint32_t vary = window_vary(wa, wb, any);
+    int np = force_np ? force_np : planes_needed(vary);
+    switch (np) {
+    case 5: return run_np<M, 5>(wa, la, wb, lb);
+    case 6: return run_np<M, 6>(wa, la, wb, lb);
+    case 7: return run_np<M, 7>(wa, la, wb, lb);
+    default: return run_np<M, 8>(wa, la, wb, lb);
+    }
+}
+
+extern "C" double harness_lane_pair(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb,
+                                    int force_np, int fill)
 {
     switch (measure) {
-    case LEVENSHTEIN: return run<LEVENSHTEIN>(a, la, b, lb);
-    case JARO: return run<JARO>(a, la, b, lb);
-    case JARO_WINKLER: return run<JARO_WINKLER>(a, la, b, lb);
-    case JACCARD: return run<JACCARD>(a, la, b, lb);
-    default: return run<SORENSEN_DICE>(a, la, b, lb);
+    case LEVENSHTEIN: return run<LEVENSHTEIN>(a, la, b, lb, force_np, (uint8_t)fill);
+    case JARO: return run<JARO>(a, la, b, lb, force_np, (uint8_t)fill);
+    case JARO_WINKLER: return run<JARO_WINKLER>(a, la, b, lb, force_np, (uint8_t)fill);
+    case JACCARD: return run<JACCARD>(a, la, b, lb, force_np, (uint8_t)fill);
+    default: return run<SORENSEN_DICE>(a, la, b, lb, force_np, (uint8_t)fill);
     }
+}
+
+// plane build vs the definition, for any 32 bytes
+extern "C" int harness_check_planes(const uint8_t *bytes32)
+{
+    uint32_t w[8];
+    std::memcpy(w, bytes32, 32);
+    uint32_t P[8];
+    build_planes<8>(w, P);
+    for (int k = 0; k < 8; ++k) {
+        uint32_t ref = 0;
+        for (int i = 0; i < 32; ++i) ref |= (uint32_t)((bytes32[i] >> k) & 1u) << i;
+        if (ref != P[k]) return k + 1;
+    }
+    uint32_t P5[5];
+    build_planes<5>(w, P5);
+    for (int k = 0; k < 5; ++k) if (P5[k] != P[k]) return 100 + k;
+    uint32_t P7[7];
+    build_planes<7>(w, P7);
+    for (int k = 0; k < 7; ++k) if (P7[k] != P[k]) return 200 + k;
+    return 0;
 }

@@ -28,7 +28,9 @@ def harness():
                                "-I", CSRC, "-o", so, srcs[0]])
     L = C.CDLL(so)
     L.harness_lane_pair.restype = C.c_double
-    L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
+    L.harness_check_planes.restype = C.c_int
+    L.harness_check_planes.argtypes = [C.c_char_p]
     return L
 
 
@@ -36,10 +38,22 @@ def bits(x):
     return struct.unpack("<Q", struct.pack("<d", x))[0]
 
 
-def lane(L, m, a, b):
+def lane(L, m, a, b, force_np=0, fill=ord("q")):
     a = a.encode() if isinstance(a, str) else a
     b = b.encode() if isinstance(b, str) else b
-    return L.harness_lane_pair(O.MEASURE_ID[m], a, len(a), b, len(b))
+    return L.harness_lane_pair(O.MEASURE_ID[m], a, len(a), b, len(b), force_np, fill)
+
+
+def test_bit_plane_transpose(harness):
+    rng = random.Random(1)
+    for _ in range(2000):
+        bs = bytes(rng.randrange(256) for _ in range(32))
+        assert harness.harness_check_planes(bs) == 0
+    for i in range(32):
+        for k in range(8):
+            bs = bytearray(32)
+            bs[i] = 1 << k
+            assert harness.harness_check_planes(bytes(bs)) == 0
 
 
 def test_lane_core_on_reference_vectors(harness):
@@ -78,9 +92,13 @@ def _rand_pairs(rng, n, alphabet, maxlen=32):
 @pytest.mark.parametrize("alphabet", [b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))])
 def test_lane_core_random_bit_exact(harness, measure, alphabet):
     rng = random.Random(hash((measure, len(alphabet))) & 0xFFFF)
-    for a, b in _rand_pairs(rng, 3000, alphabet):
-        got = lane(harness, measure, a, b)
+    for n, (a, b) in enumerate(_rand_pairs(rng, 3000, alphabet)):
         exp = O.pair(measure, a, b)
+        # planes chosen like the kernel does, with window filler from the same alphabet ...
+        got = lane(harness, measure, a, b, 0, alphabet[n % len(alphabet)])
+        assert bits(got) == bits(exp), (measure, a, b, got, exp)
+        # ... and forced to the widest settings (zero filler = end of buffer)
+        got = lane(harness, measure, a, b, 7 + (n & 1), 0)
         assert bits(got) == bits(exp), (measure, a, b, got, exp)
 
 
