@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense a bench_support/profile.sh output directory into a small text summary (for profiles/)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def main():
+    out = sys.argv[1]
+    st = find(os.path.join(out, "trace"), "*kernel_stats.csv")
+    if st:
+        print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+        for r in csv.DictReader(open(st)):
+            print(f'{short(r["Name"]):70s} calls={r["Calls"]:>4s} avg_us={float(r["AverageNs"])/1e3:10.1f} '
+                  f'min_us={float(r["MinNs"])/1e3:10.1f} max_us={float(r["MaxNs"])/1e3:10.1f} pct={r["Percentage"]}')
+    for grp in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        f = find(os.path.join(out, grp), "*counter_collection.csv")
+        if not f:
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(f"== {grp} (per-dispatch mean) ==")
+        for k, cs in acc.items():
+            if "strsim" not in k:
+                continue
+            print(" ", k)
+            for c, v in sorted(cs.items()):
+                print(f"     {c:24s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+
+
+if __name__ == "__main__":
+    main()

@@ -65,9 +65,23 @@ __device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes, everything in registers (no LDS).
+// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes, match masks and DP state in registers.
+//
+// The kernel is VALU-bound (rocprof: VALU ~99 % busy on 32-bit integer ops at 4 cycles per wave64
+// instruction), and every lane of a wave runs as many DP columns as the longest text in the wave.
+// So a 4-wave workgroup takes a block of 512 consecutive rows, buckets them by the number of DP
+// columns they need (8 buckets of 4; LDS counters + a 512-entry permutation) and processes them as 8
+// rounds of 64 rows of similar length -- wave w runs rounds w and 7-w (short + long = balanced).
+// A round runs only as many columns as ITS longest text, rounded up to 4.  The block's offsets are
+// read once, coalesced, and staged in LDS; the strings are fetched per lane (every line of the block
+// is touched by the same CU within a few microseconds: L1/L2 hits); results are staged in LDS and
+// stored coalesced.
 // ------------------------------------------------------------------------------------------------
-constexpr int LANE_BLOCK = 256; // 4 independent waves per workgroup
+constexpr int LANE_BLOCK = 256;                  // threads per workgroup
+constexpr int LANE_WAVES = LANE_BLOCK / 64;      // 4
+constexpr int LANE_ROUNDS = 2 * LANE_WAVES;      // 8 rounds of 64 rows per block
+constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
+constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coalesced phases (2)
 
 // 4 * ceil(max over the wave of v / 4), at least 4 (v <= 32): three ballots, result in an SGPR
 __device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
@@ -87,52 +101,131 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
                                                            double *__restrict__ out, uint64_t n,
                                                            unsigned long long *__restrict__ slowmask)
 {
+    __shared__ uint32_t s_cnt[2][8];                    // bucket counters (double-buffered by block parity)
+    __shared__ unsigned long long s_late[2][LANE_ROUNDS]; // rows found non-ASCII after their bytes were loaded
+    __shared__ uint16_t s_perm[LANE_ROWS];
+    __shared__ uint32_t s_a0[LANE_ROWS];
+    __shared__ uint32_t s_b0[LANE_ROWS];
+    __shared__ uint32_t s_len[LANE_ROWS];               // la | lb << 16, or ~0 for rows this kernel skips
+    __shared__ double s_out[LANE_ROWS];
+    __shared__ double s_levtab[MEASURE == LEVENSHTEIN ? 33 * 33 : 1];
+
+    // Levenshtein distance and the multiset intersection do not depend on the argument order
+    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
+    const uint32_t tid = threadIdx.x;
     const uint32_t lane = lane_id();
+    const uint32_t wv = tid >> 6;
+    if (MEASURE == LEVENSHTEIN) {
+        // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: same IEEE division as the
+        // epilogue, done once per workgroup instead of once per pair
+        for (uint32_t i = tid; i < 33u * 33u; i += LANE_BLOCK) {
+            const uint32_t d = i / 33u, m = i % 33u;
+            s_levtab[i] = m ? epilogue_levenshtein(d, m, m) : 0.0;
+        }
+    }
     const uint32_t totalA = offA[rowsA];
     const uint32_t totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
-    const uint64_t nchunks = (n + 63u) >> 6;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * (LANE_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * (LANE_BLOCK / 64);
+    const uint64_t nblocks = (n + (LANE_ROWS - 1)) / LANE_ROWS;
+    uint32_t par = 0;
 
-    for (uint64_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
-        const uint64_t row = chunk * 64u + lane;
-        const bool valid = row < n;
-        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-        if (valid) {
-            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-            a0 = offA[ra]; a1 = offA[ra + 1];
-            b0 = offB[rb]; b1 = offB[rb + 1];
-        }
-        const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
-        uint32_t wa[8], wb[8];
+    for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, par ^= 1u) {
+        const uint64_t row0 = blk * LANE_ROWS;
+        if (tid < 8u) { s_cnt[par][tid] = 0u; s_late[par][tid] = 0ull; }
+        __syncthreads();
+        // ---- phase 1 (coalesced): offsets -> lengths -> bucket + rank; stage offsets in LDS ---------
+        uint32_t key[LANE_RPT], rank[LANE_RPT];
+        unsigned long long skip[LANE_RPT]; // per 64-row chunk (q * 4 + wv): rows this kernel will not write
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
-        bool fast = valid && la8 <= 32u && lb8 <= 32u;
-        uint32_t vary = 0u;
-        if (fast) {
-            load_window32(valA, a0, totalA, wa);
-            load_window32(valB, b0, totalB, wb);
-            // conservative tests on the whole 32-byte windows (bytes past a string belong to its
-            // neighbours): any high bit sends the row to the code-point kernel; the varying low bits
-            // decide how many bit-planes the match masks need
-            uint32_t any;
-            vary = window_vary(wa, wb, any);
-            fast = (any & 0x80u) == 0u;
+        for (int q = 0; q < LANE_RPT; ++q) {
+            const uint32_t i = q * LANE_BLOCK + tid;
+            const uint64_t row = row0 + i;
+            const bool valid = row < n;
+            uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (valid) {
+                const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                a0 = offA[ra]; a1 = offA[ra + 1];
+                b0 = offB[rb]; b1 = offB[rb + 1];
+            }
+            const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
+            const bool mine = valid && la8 <= 32u && lb8 <= 32u;
+            skip[q] = __ballot(!mine);
+            // bucket by the number of DP columns the pair will run (SYMMETRIC measures walk the shorter string)
+            const uint32_t steps = SYMMETRIC ? (la8 < lb8 ? la8 : lb8) : la8;
+            key[q] = mine ? (((steps ? steps : 1u) - 1u) >> 2) : 7u;
+            rank[q] = atomicAdd(&s_cnt[par][key[q]], 1u);
+            s_a0[i] = a0;
+            s_b0[i] = b0;
+            s_len[i] = mine ? (la8 | (lb8 << 16)) : 0xFFFFFFFFu;
         }
-        const unsigned long long slow = __ballot(valid && !fast);
-        if (lane == 0) slowmask[chunk] = slow;
-        if (__ballot(fast) == 0ull) continue;
+        __syncthreads();
+        {
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = s_cnt[par][k];
+#pragma unroll
+            for (int q = 0; q < LANE_RPT; ++q) {
+                uint32_t base = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) base += ((uint32_t)k < key[q]) ? c[k] : 0u;
+                s_perm[base + rank[q]] = (uint16_t)(q * LANE_BLOCK + tid);
+            }
+        }
+        __syncthreads();
 
-        const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
-        const uint32_t tmax = wave_max_round4(la);
-        const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
-        const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
-        double r;
-        if (need7) r = lane_pair_result<MEASURE, 7>(wa, la, wb, lb, tmax);
-        else if (need6) r = lane_pair_result<MEASURE, 6>(wa, la, wb, lb, tmax);
-        else r = lane_pair_result<MEASURE, 5>(wa, la, wb, lb, tmax);
-        if (fast) out[row] = r;
+        // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint32_t r = rr ? (uint32_t)(LANE_ROUNDS - 1) - wv : wv;
+            const uint32_t idx = s_perm[r * 64u + lane];
+            const uint32_t a0 = s_a0[idx], b0 = s_b0[idx];
+            const uint32_t len = s_len[idx];
+            uint32_t la8 = len & 0xFFFFu, lb8 = len >> 16;
+            uint32_t wa[8], wb[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
+            bool fast = len != 0xFFFFFFFFu;
+            uint32_t vary = 0u;
+            if (fast) {
+                load_window32(valA, a0, totalA, wa);
+                load_window32(valB, b0, totalB, wb);
+                // conservative tests on the whole 32-byte windows (bytes past a string belong to its
+                // neighbours): any high bit sends the row to the code-point kernel; the varying low
+                // bits decide how many bit-planes the match masks need
+                uint32_t any;
+                vary = window_vary(wa, wb, any);
+                if (any & 0x80u) {
+                    fast = false;
+                    atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
+                }
+            }
+            if (__ballot(fast) == 0ull) continue;
+            if (SYMMETRIC && la8 > lb8) { // walk the shorter string: swap roles
+#pragma unroll
+                for (int d = 0; d < 8; ++d) { const uint32_t t = wa[d]; wa[d] = wb[d]; wb[d] = t; }
+                const uint32_t t = la8; la8 = lb8; lb8 = t;
+            }
+            const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
+            const uint32_t tmax = wave_max_round4(la);
+            const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
+            const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
+            double res;
+            if (need7) res = lane_pair_result<MEASURE, 7>(wa, la, wb, lb, tmax, s_levtab);
+            else if (need6) res = lane_pair_result<MEASURE, 6>(wa, la, wb, lb, tmax, s_levtab);
+            else res = lane_pair_result<MEASURE, 5>(wa, la, wb, lb, tmax, s_levtab);
+            if (fast) s_out[idx] = res;
+        }
+        __syncthreads();
+        // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
+#pragma unroll
+        for (int q = 0; q < LANE_RPT; ++q) {
+            const uint32_t i = q * LANE_BLOCK + tid;
+            const uint64_t row = row0 + i;
+            const unsigned long long sk = skip[q] | s_late[par][i >> 6];
+            if (!((sk >> lane) & 1ull)) out[row] = s_out[i];
+            if (lane == 0u && row < n)
+                slowmask[row >> 6] = sk & (n - row >= 64u ? ~0ull : ((1ull << (n - row)) - 1ull));
+        }
     }
 }
 
@@ -408,7 +501,7 @@ template <int M>
 static void launch_pair(const LaunchArgs &a)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
-    const uint64_t nblk = (nchunks + (LANE_BLOCK / 64) - 1) / (LANE_BLOCK / 64);
+    const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
     const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
     const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);

@@ -74,6 +74,26 @@ STRSIM_HD uint32_t bit_fill(uint32_t w, int off)
 #endif
 }
 
+// Three-input boolean function with truth table TT (a = 0xF0, b = 0xCC, c = 0xAA): one v_bitop3_b32.
+template <int TT>
+STRSIM_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    if (TT & 0x01) r |= ~a & ~b & ~c;
+    if (TT & 0x02) r |= ~a & ~b & c;
+    if (TT & 0x04) r |= ~a & b & ~c;
+    if (TT & 0x08) r |= ~a & b & c;
+    if (TT & 0x10) r |= a & ~b & ~c;
+    if (TT & 0x20) r |= a & ~b & c;
+    if (TT & 0x40) r |= a & b & ~c;
+    if (TT & 0x80) r |= a & b & c;
+    return r;
+#endif
+}
+
 // 8x8 bit-matrix transpose of the eight bytes {lo, hi}: afterwards byte k holds bit k of the eight
 // source bytes (bit i of byte k = bit k of source byte i).  Three block-swap rounds (1, 2, 4 bits).
 STRSIM_HD void transpose8x8(uint32_t &lo, uint32_t &hi)
@@ -132,7 +152,7 @@ STRSIM_HD uint32_t eq_mask(const uint32_t (&P)[NP], uint32_t valid, uint32_t w, 
 {
     uint32_t acc = valid;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) acc &= ~(P[k] ^ bit_fill(w, 8 * byte + k));
+    for (int k = 0; k < NP; ++k) acc = bitop3<0x90>(acc, P[k], bit_fill(w, 8 * byte + k)); // acc & ~(P_k ^ m_k)
     return acc;
 }
 
@@ -181,13 +201,13 @@ STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tm
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const uint32_t Eq = eq_mask<NP>(P, valid, wt[g], jj);
-            const uint32_t D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
-            const uint32_t HP = Mv | ~(D0 | Pv);
+            const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq | Mv); // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
+            const uint32_t HP = bitop3<0xF1>(Mv, D0, Pv);                    // Mv | ~(D0 | Pv)
             const uint32_t HN = Pv & D0;
             hp = (hp << 1) | (HP >> 31);
             hn = (hn << 1) | (HN >> 31);
             const uint32_t X = (HP << 1) | 1u;
-            Pv = (HN << 1) | ~(D0 | X);
+            Pv = bitop3<0xF1>(HN << 1, D0, X);                               // (HN << 1) | ~(D0 | X)
             Mv = D0 & X;
         }
         nit += 4u;
@@ -335,9 +355,10 @@ STRSIM_HD double epilogue_sorensen_dice(uint64_t isect, uint64_t la, uint64_t lb
 // code: every formula below yields exactly 1.0 for equal strings.
 // NP: number of low bits that tell the pair's bytes apart (planes_needed); tmax: uniform bound >= la.
 // ---------------------------------------------------------------------------------------------
+// levtab: optional 33x33 table of 1.0 - dist/den (index dist*33 + den), else nullptr.
 template <int MEASURE, int NP>
 STRSIM_HD double lane_pair_result(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
-                                  uint32_t tmax)
+                                  uint32_t tmax, const double *levtab = nullptr)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P); // pattern = b
@@ -349,7 +370,7 @@ STRSIM_HD double lane_pair_result(const uint32_t (&wa)[8], uint32_t la, const ui
 #pragma unroll
         for (int k = 0; k < NP; ++k) P[k] <<= s;
         const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
-        r = epilogue_levenshtein(dist, la1, lb1);
+        r = levtab ? levtab[dist * 33u + (la1 > lb1 ? la1 : lb1)] : epilogue_levenshtein(dist, la1, lb1);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
         jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
