@@ -434,9 +434,18 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     const uint64_t nchunks = (n + 63u) >> 6;
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
 
-    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        unsigned long long mask = slowmask[chunk];
-        mask = ((unsigned long long)uniform((uint32_t)(mask >> 32)) << 32) | uniform((uint32_t)mask);
+    // scan the mask words 64 at a time (one per lane, coalesced); visit the non-zero ones
+    for (uint64_t cbase = (uint64_t)blockIdx.x * 64u; cbase < nchunks; cbase += (uint64_t)gridDim.x * 64u) {
+      const uint64_t cmine = cbase + lane;
+      const unsigned long long mword = cmine < nchunks ? slowmask[cmine] : 0ull;
+      unsigned long long pending = __ballot(mword != 0ull);
+      while (pending != 0ull) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+        pending &= pending - 1ull;
+        const uint64_t chunk = cbase + src;
+        unsigned long long mask =
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
         while (mask != 0ull) {
             const uint32_t bitpos = (uint32_t)__builtin_ctzll(mask);
             mask &= mask - 1ull;
@@ -484,6 +493,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
             }
             if (lane == 0u) out[row] = r;
         }
+      }
     }
     if (lane == 0u && my_rows != 0u) {
         atomicAdd(&status->wave_rows, my_rows);
