@@ -235,6 +235,7 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
     la.out = out; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
     la.lane_grid = c->num_cu * 5;  // 256-thread workgroups; VGPRs admit 5 per CU, the rest of the blocks are grid-strided
+    la.wide_grid = c->num_cu * 3;
     la.wave_grid = c->num_cu * 8;
     la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;
     if (c->timing) {

@@ -21,7 +21,7 @@ struct LaunchArgs {
     unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
     DevStatus *status;            // zeroed by the caller
     hipStream_t stream;
-    int lane_grid, wave_grid;     // max workgroups for the two kernels
+    int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)
 };
 

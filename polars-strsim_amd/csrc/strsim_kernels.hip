@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "strsim_lane_core.h"
+#include "strsim_lane_wide.h"
 #include "strsim_kernels.h"
 
 namespace strsim {
@@ -226,6 +227,189 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
             if (lane == 0u && row < n)
                 slowmask[row >> 6] = sk & (n - row >= 64u ? ~0ull : ((1ull << (n - row)) - 1ull));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lane_wide: one pair per lane for the rows k_lane_pairs left behind whose strings are 33..128 ASCII
+// bytes: W = 2 (<= 64) or W = 4 (<= 128) word masks (strsim_lane_wide.h).  A workgroup takes a span of
+// WIDE_SPAN mask words (2048 rows), collects the flagged rows of each width class into LDS lists and runs
+// them 64 at a time; finished rows are cleared from the mask, the rest (non-ASCII, longer, empty side)
+// stay for k_wave_pairs.  With nothing flagged a span costs one 256-byte read.
+// ------------------------------------------------------------------------------------------------
+constexpr int WIDE_BLOCK = 256;
+constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
+constexpr int WIDE_SPAN = 32;               // mask words (64-row chunks) per span
+constexpr int WIDE_ROWS = WIDE_SPAN * 64;   // 2048 rows
+constexpr int WIDE_MAXW = 4;
+
+// NDW dwords of vals[start, start + 4*NDW); bytes outside [0, total) read as 0.  start may be negative.
+template <int NDW>
+__device__ __forceinline__ void load_window_any(const uint8_t *__restrict__ vals, int64_t start, uint32_t total,
+                                                uint32_t (&w)[NDW])
+{
+    if (start >= 0 && start + 4 * NDW <= (int64_t)total) {
+        const uint8_t *p = vals + start;
+#pragma unroll
+        for (int q = 0; q < NDW / 4; ++q) {
+            const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(p + 16 * q);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll 1
+        for (int d = 0; d < NDW; ++d) {
+            uint32_t v = 0u;
+            for (int k = 0; k < 4; ++k) {
+                const int64_t idx = start + 4 * d + k;
+                if (idx >= 0 && idx < (int64_t)total) v |= (uint32_t)vals[idx] << (8 * k);
+            }
+            // static register index: select by compare chain
+#pragma unroll
+            for (int e = 0; e < NDW; ++e)
+                if (e == d) w[e] = v;
+        }
+    }
+}
+
+struct LdsTxt {
+    const uint32_t *col; // &s_txt[wave][0][lane], dword g at col[g * 64]
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return col[g * 64u]; }
+};
+struct LdsFaStore {
+    uint32_t *col;
+    __device__ __forceinline__ void operator()(uint32_t q, uint32_t v) const { col[q * 64u] = v; }
+};
+struct LdsFaLoad {
+    const uint32_t *col;
+    __device__ __forceinline__ uint32_t operator()(uint32_t q) const { return col[q * 64u]; }
+};
+
+// max over the wave of v (v <= 255), uniform
+__device__ __forceinline__ uint32_t wave_max_u8(uint32_t v)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 7; b >= 0; --b)
+        if (__ballot(v >= (m | (1u << b))) != 0ull) m |= 1u << b;
+    return m;
+}
+
+template <int MEASURE, int W>
+__device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
+                                           const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
+                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t *txt_col, uint32_t *fa_col,
+                                           bool &done, double &res)
+{
+    uint32_t ta[8 * W], wp[8 * W];
+#pragma unroll
+    for (int d = 0; d < 8 * W; ++d) { ta[d] = 0u; wp[d] = 0u; }
+    uint32_t b0w = 0u;
+    bool fast = has;
+    uint32_t vary = 0u;
+    if (has) {
+        load_window_any<8 * W>(valA, (int64_t)a0, totalA, ta);
+        // Levenshtein wants b left-aligned: take the window that ENDS at the end of b
+        const int64_t bstart = MEASURE == LEVENSHTEIN ? (int64_t)b0 + (int64_t)lb - 32 * W : (int64_t)b0;
+        load_window_any<8 * W>(valB, bstart, totalB, wp);
+        if (MEASURE == JARO_WINKLER) b0w = wp[0];
+        uint32_t o = ta[0] | wp[0], n = ta[0] & wp[0];
+#pragma unroll
+        for (int d = 1; d < 8 * W; ++d) { o |= ta[d] | wp[d]; n &= ta[d] & wp[d]; }
+        uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
+        uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
+        vary = (o8 ^ n8) & 0xFFu;
+        fast = (o8 & 0x80u) == 0u; // any high bit in the windows: leave the row to the code-point kernel
+    }
+#pragma unroll
+    for (int d = 0; d < 8 * W; ++d) txt_col[d * 64] = ta[d];
+    const uint32_t lae = fast ? la : 1u, lbe = fast ? lb : 1u;
+    const uint32_t ng4 = (wave_max_u8(fast ? la : 0u) + 3u) >> 2;
+    done = false;
+    if (__ballot(fast) == 0ull) return;
+    const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
+    const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
+    const LdsTxt txt{txt_col};
+    const LdsFaStore fst{fa_col};
+    const LdsFaLoad fld{fa_col};
+    if (need7) res = lane_wide_result<MEASURE, 7, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    else if (need6) res = lane_wide_result<MEASURE, 6, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    done = fast;
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__restrict__ offA,
+                                                          const uint8_t *__restrict__ valA, uint64_t rowsA,
+                                                          const uint32_t *__restrict__ offB,
+                                                          const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                          double *__restrict__ out, uint64_t n,
+                                                          unsigned long long *__restrict__ slowmask)
+{
+    __shared__ unsigned long long s_mask[WIDE_SPAN];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint16_t s_list[2][WIDE_ROWS];
+    __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
+    __shared__ uint32_t s_fa[WIDE_WAVES][WIDE_MAXW + 1][64];
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint64_t nchunks = (n + 63u) >> 6;
+    const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
+
+    for (uint64_t span = blockIdx.x; span < nspans; span += gridDim.x) {
+        const uint64_t c0 = span * WIDE_SPAN;
+        if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
+        if (tid < 2u) s_cnt[tid] = 0u;
+        __syncthreads();
+        const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
+        if (any) {
+            // ---- collect: rows with 33..128-byte strings on the longer side and a non-empty shorter side
+#pragma unroll 1
+            for (int k = 0; k < WIDE_ROWS / WIDE_BLOCK; ++k) {
+                const uint32_t i = k * WIDE_BLOCK + tid;
+                if ((s_mask[i >> 6] >> (i & 63u)) & 1ull) {
+                    const uint64_t row = c0 * 64u + i;
+                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                    const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
+                    const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
+                    if (mx > 32u && mx <= 128u && mn >= 1u) {
+                        const uint32_t cls = mx > 64u ? 1u : 0u;
+                        s_list[cls][atomicAdd(&s_cnt[cls], 1u)] = (uint16_t)i;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- rounds of 64 rows, dealt over the waves
+            const uint32_t n2 = s_cnt[0], n4 = s_cnt[1];
+            const uint32_t r2 = (n2 + 63u) >> 6, r4 = (n4 + 63u) >> 6;
+            for (uint32_t r = wv; r < r2 + r4; r += WIDE_WAVES) {
+                const uint32_t cls = r < r2 ? 0u : 1u;
+                const uint32_t li = (cls ? r - r2 : r) * 64u + lane;
+                const bool has = li < (cls ? n4 : n2);
+                const uint32_t i = has ? s_list[cls][li] : 0u;
+                const uint64_t row = c0 * 64u + i;
+                uint32_t a0 = 0, la = 0, b0 = 0, lb = 0;
+                if (has) {
+                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                    a0 = offA[ra]; la = offA[ra + 1] - a0;
+                    b0 = offB[rb]; lb = offB[rb + 1] - b0;
+                }
+                bool done = false;
+                double res = 0.0;
+                if (cls == 0u)
+                    wide_round<MEASURE, 2>(valA, totalA, valB, totalB, has, a0, la, b0, lb, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                else
+                    wide_round<MEASURE, 4>(valA, totalA, valB, totalB, has, a0, la, b0, lb, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                if (done) {
+                    out[row] = res;
+                    atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
+                }
+            }
+            __syncthreads();
+            if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
+        }
+        __syncthreads();
     }
 }
 
@@ -434,15 +618,18 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     const uint64_t nchunks = (n + 63u) >> 6;
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
 
-    // scan the mask words 64 at a time (one per lane, coalesced); visit the non-zero ones
-    for (uint64_t cbase = (uint64_t)blockIdx.x * 64u; cbase < nchunks; cbase += (uint64_t)gridDim.x * 64u) {
-      const uint64_t cmine = cbase + lane;
+    // Chunks are dealt round-robin over the waves (chunk = k * nwaves + wave) so that a column full of long rows
+    // spreads over the whole chip; each wave fetches the mask words of its next 64 chunks with one load
+    // (lane k holds chunk k's word) and visits the non-zero ones.
+    const uint64_t nwaves = gridDim.x;
+    for (uint64_t kbase = 0; kbase * nwaves < nchunks; kbase += 64u) {
+      const uint64_t cmine = (kbase + lane) * nwaves + blockIdx.x;
       const unsigned long long mword = cmine < nchunks ? slowmask[cmine] : 0ull;
       unsigned long long pending = __ballot(mword != 0ull);
       while (pending != 0ull) {
         const uint32_t src = (uint32_t)__builtin_ctzll(pending);
         pending &= pending - 1ull;
-        const uint64_t chunk = cbase + src;
+        const uint64_t chunk = (kbase + src) * nwaves + blockIdx.x;
         unsigned long long mask =
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
@@ -518,6 +705,12 @@ static void launch_pair(const LaunchArgs &a)
     hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
+    {
+        const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
+        const uint64_t g3 = nspans < (uint64_t)a.wide_grid ? nspans : (uint64_t)a.wide_grid;
+        hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
+    }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status);
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);

@@ -1,0 +1,269 @@
+// strsim_lane_wide.h -- per-lane cores for strings of up to 32*W bytes (W = 2: 64, W = 4: 128), ASCII.
+//
+// Same bit-sliced formulation as strsim_lane_core.h, with every mask W words wide.  The text is not
+// kept in registers: it is read one dword (4 bytes) at a time through `txt(g)` (an LDS column per lane
+// on the GPU, a plain array in the CPU harness), so the column loop is a runtime loop of 4-step bodies
+// and the code stays small for any W.  Host/device portable; bit-exact against the oracle by
+// construction (tests/test_lane_core_cpu.py).
+//
+// Semantics restated (reference = /root/reference/src/expressions/strsim.rs):
+//   lev_wide       -> integer edit distance of Levenshtein::compute      (:141-160)
+//   jaro_wide      -> (m, t) of Jaro::compute                            (:200-237)
+//   isect_wide     -> sum of min(countA[c], countB[c]) of Jaccard/Dice   (:297-305, :333-341)
+#pragma once
+#include "strsim_lane_core.h"
+
+namespace strsim {
+
+// ---- W-word helpers (word 0 = least significant) -------------------------------------------------
+template <int W>
+STRSIM_HD void low_ones_wide(uint32_t k, uint32_t (&m)[W]) // ones at bits [0, k), k <= 32*W
+{
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t lo = 32u * (uint32_t)w;
+        m[w] = k <= lo ? 0u : low_ones(k - lo);
+    }
+}
+
+// x = (x << 1) | in  (in = 0 or 1), as an add-with-carry chain
+template <int W>
+STRSIM_HD void shl1_in(uint32_t (&x)[W], uint32_t in)
+{
+    uint32_t c = in;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t top = x[w] >> 31;
+        x[w] = (x[w] << 1) | c;
+        c = top;
+    }
+}
+
+// lowest set bit of the W-word integer x (all zero if x == 0): x & ~(x - 1)
+template <int W>
+STRSIM_HD void lowest_bit_wide(const uint32_t (&x)[W], uint32_t (&bit)[W])
+{
+    uint32_t borrow = 1u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t d = x[w] - borrow;
+        borrow = (x[w] < borrow) ? 1u : 0u;
+        bit[w] = x[w] & ~d;
+    }
+}
+
+template <int W>
+STRSIM_HD uint32_t any_wide(const uint32_t (&x)[W])
+{
+    uint32_t o = x[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) o |= x[w];
+    return o;
+}
+
+// Planes of a 32*W-byte window (dwords wp[0 .. 8W)): P[k][w] bit i = bit k of byte 32w + i.
+template <int NP, int W>
+STRSIM_HD void build_planes_wide(const uint32_t (&wp)[8 * W], uint32_t (&P)[NP][W])
+{
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint32_t grp[8], pl[NP];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) grp[d] = wp[8 * w + d];
+        build_planes<NP>(grp, pl);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) P[k][w] = pl[k];
+    }
+}
+
+// match mask of byte `byte` (static 0..3) of dword `c4` against all 32*W pattern positions
+template <int NP, int W>
+STRSIM_HD void eq_wide(const uint32_t (&P)[NP][W], const uint32_t (&valid)[W], uint32_t c4, int byte, uint32_t (&Eq)[W])
+{
+    uint32_t m[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) m[k] = bit_fill(c4, 8 * byte + k);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint32_t acc = valid[w];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc = bitop3<0x90>(acc, P[k][w], m[k]);
+        Eq[w] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Levenshtein, W-word Myers/Hyyro.  The pattern b is LEFT-aligned in the 32*W-bit vector: its planes
+// come from the window that ENDS at the end of b (the caller loads bytes [end - 32W, end)), so position j
+// of b is bit j + s, s = 32W - lb, and the score row is the top bit.  Bits below s are the fictitious
+// shared prefix (see strsim_lane_core.h).  The running score is updated only while the column index is
+// below the lane's own la (ng4 = number of text dwords the wave walks, uniform).  la, lb >= 1.
+// ---------------------------------------------------------------------------------------------
+template <int NP, int W, class Txt>
+STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t ng4, const uint32_t (&P)[NP][W], uint32_t lb)
+{
+    const uint32_t s = 32u * W - lb;
+    uint32_t lowm[W], valid[W], Pv[W], Mv[W];
+    low_ones_wide<W>(s, lowm);
+#pragma unroll
+    for (int w = 0; w < W; ++w) { valid[w] = ~lowm[w]; Pv[w] = valid[w]; Mv[w] = lowm[w]; }
+    uint32_t score = lb;
+    for (uint32_t g = 0; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            uint32_t Eq[W];
+            eq_wide<NP, W>(P, valid, c4, jj, Eq);
+            // t = (Eq & Pv) + Pv  (W-word add)
+            uint32_t D0[W];
+            uint32_t carry = 0u;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t x = Eq[w] & Pv[w];
+                const uint32_t s1 = x + Pv[w];
+                const uint32_t c1 = s1 < x ? 1u : 0u;
+                const uint32_t s2 = s1 + carry;
+                const uint32_t c2 = s2 < s1 ? 1u : 0u;
+                carry = c1 | c2;
+                D0[w] = bitop3<0xBE>(s2, Pv[w], Eq[w] | Mv[w]);
+            }
+            uint32_t HP[W], HN[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) { HP[w] = bitop3<0xF1>(Mv[w], D0[w], Pv[w]); HN[w] = Pv[w] & D0[w]; }
+            const uint32_t col = 4u * g + (uint32_t)jj;
+            const uint32_t delta = (HP[W - 1] >> 31) - (HN[W - 1] >> 31);
+            score += col < la ? delta : 0u;
+            shl1_in<W>(HP, 1u); // X
+            shl1_in<W>(HN, 0u);
+#pragma unroll
+            for (int w = 0; w < W; ++w) { Pv[w] = bitop3<0xF1>(HN[w], D0[w], HP[w]); Mv[w] = D0[w] & HP[w]; }
+        }
+    }
+    return score;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jaro matching, W words.  Pattern = b (right-aligned planes: bit j = b[j]), text = a through txt().
+// `fa_store(q, word)` / `fa_load(q)` keep the flagged-a bits of columns [32q, 32q+32) between the two
+// passes (an LDS column per lane on the GPU).  la, lb >= 1.  Returns m and t (not halved).
+// ---------------------------------------------------------------------------------------------
+template <int NP, int W, class Txt, class FaStore, class FaLoad>
+STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W],
+                         const FaStore &fa_store, const FaLoad &fa_load, uint32_t &m_out, uint32_t &t_out)
+{
+    const uint32_t mx = la > lb ? la : lb;
+    const uint32_t half = mx >> 1;
+    const uint32_t bound = (half ? half : 1u) - 1u;
+    uint32_t lbmask[W], himask[W], lomask[W], fb[W];
+    low_ones_wide<W>(lb, lbmask);
+    low_ones_wide<W>((bound + 1u) < lb ? (bound + 1u) : lb, himask);
+#pragma unroll
+    for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
+    uint32_t fa_acc = 0u;
+    for (uint32_t g = 0; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t i = 4u * g + (uint32_t)ii;
+            const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
+            uint32_t Eq[W], cand[W], bit[W];
+            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+#pragma unroll
+            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x20>(Eq[w] & himask[w], lomask[w] | fb[w], live); // a & ~b & c
+            lowest_bit_wide<W>(cand, bit);
+#pragma unroll
+            for (int w = 0; w < W; ++w) fb[w] |= bit[w];
+            const uint32_t matched = any_wide<W>(bit) ? 1u : 0u;
+            fa_acc = (fa_acc >> 1) | (matched << 31); // column i ends at bit (i & 31) once its 32-group is complete
+            shl1_in<W>(himask, 1u);
+#pragma unroll
+            for (int w = 0; w < W; ++w) himask[w] &= lbmask[w];
+            shl1_in<W>(lomask, i >= bound ? 1u : 0u);
+        }
+        if ((g & 7u) == 7u) { fa_store(g >> 3, fa_acc); fa_acc = 0u; }
+    }
+    if ((ng4 & 7u) != 0u) fa_store(ng4 >> 3, fa_acc >> (32u - 4u * (ng4 & 7u))); // partial last group: right-align
+
+    uint32_t rest[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) rest[w] = fb[w];
+    uint32_t t = 0u, fa_cur = 0u;
+    for (uint32_t g = 0; g < ng4; ++g) {
+        if ((g & 7u) == 0u) fa_cur = fa_load(g >> 3);
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t on = bit_fill(fa_cur, 0);
+            fa_cur >>= 1;
+            uint32_t Eq[W], jbit[W], miss[W];
+            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+            lowest_bit_wide<W>(rest, jbit);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                jbit[w] &= on;
+                rest[w] ^= jbit[w];
+                miss[w] = jbit[w] & ~Eq[w];
+            }
+            t += any_wide<W>(miss) ? 1u : 0u;
+        }
+    }
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) m += popc32(fb[w]);
+    m_out = m;
+    t_out = t;
+}
+
+// Multiset intersection size, W words (see multiset_isect32).
+template <int NP, int W, class Txt>
+STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W])
+{
+    uint32_t lbmask[W], used[W];
+    low_ones_wide<W>(lb, lbmask);
+#pragma unroll
+    for (int w = 0; w < W; ++w) used[w] = 0u;
+    for (uint32_t g = 0; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t live = (4u * g + (uint32_t)ii) < la ? 0xFFFFFFFFu : 0u;
+            uint32_t Eq[W], cand[W], bit[W];
+            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+#pragma unroll
+            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x20>(Eq[w], used[w], live);
+            lowest_bit_wide<W>(cand, bit);
+#pragma unroll
+            for (int w = 0; w < W; ++w) used[w] |= bit[w];
+        }
+    }
+    uint32_t n = 0u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) n += popc32(used[w]);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One lane's result, strings of 1..32*W ASCII bytes each (the empty cases never reach the wide path).
+// wp = the pattern window: for Levenshtein the 32W bytes that END at the end of b, else the 32W bytes
+// that START at b.  a0w / b0w = first dwords of a and b (Jaro-Winkler prefix).
+// ---------------------------------------------------------------------------------------------
+template <int MEASURE, int NP, int W, class Txt, class FaStore, class FaLoad>
+STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t ng4, const uint32_t (&wp)[8 * W], uint32_t lb,
+                                  uint32_t a0w, uint32_t b0w, const FaStore &fa_store, const FaLoad &fa_load)
+{
+    uint32_t P[NP][W];
+    build_planes_wide<NP, W>(wp, P);
+    if (MEASURE == LEVENSHTEIN) {
+        return epilogue_levenshtein(lev_wide<NP, W>(txt, la, ng4, P, lb), la, lb);
+    } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        uint32_t m, t;
+        jaro_wide<NP, W>(txt, la, ng4, lb, P, fa_store, fa_load, m, t);
+        const double j = epilogue_jaro(m, t, la, lb);
+        return MEASURE == JARO ? j : epilogue_jaro_winkler(j, common_prefix4(a0w, la, b0w, lb));
+    } else {
+        const uint32_t isect = isect_wide<NP, W>(txt, la, ng4, lb, P);
+        return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+    }
+}
+
+} // namespace strsim

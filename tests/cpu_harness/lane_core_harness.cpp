@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstring>
 #include "strsim_lane_core.h"
+#include "strsim_lane_wide.h"
 
 using namespace strsim;
 
@@ -66,4 +67,66 @@ extern "C" int harness_check_planes(const uint8_t *bytes32)
     build_planes<7>(w, P7);
     for (int k = 0; k < 7; ++k) if (P7[k] != P[k]) return 200 + k;
     return 0;
+}
+
+// ---- wide (W-word) cores -------------------------------------------------------------------------
+struct ArrTxt { const uint32_t *w; uint32_t operator()(uint32_t g) const { return w[g]; } };
+struct FaSt { uint32_t *f; void operator()(uint32_t q, uint32_t v) const { f[q] = v; } };
+struct FaLd { const uint32_t *f; uint32_t operator()(uint32_t q) const { return f[q]; } };
+
+template <int M, int NP, int W>
+static double run_wide_np(const uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w)
+{
+    uint32_t fa[W + 1] = {0};
+    const uint32_t ng4 = (la + 3u) / 4u;
+    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, ng4, wp, lb, ta[0], b0w, FaSt{fa}, FaLd{fa});
+}
+
+template <int M, int W>
+static double run_wide(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
+{
+    uint32_t ta[8 * W], wp[8 * W], wbn[8 * W];
+    uint8_t buf[32 * W];
+    std::memset(ta, fill, sizeof ta);
+    std::memcpy(ta, a, la);
+    std::memset(buf, fill, sizeof buf);
+    std::memcpy(buf, b, lb);
+    std::memcpy(wbn, buf, sizeof buf);            // natural window (starts at b)
+    if (M == LEVENSHTEIN) {                       // window that ENDS at the end of b
+        std::memset(buf, fill, sizeof buf);
+        std::memcpy(buf + 32 * W - lb, b, lb);
+    }
+    std::memcpy(wp, buf, sizeof buf);
+    // varying bits over both windows
+    uint32_t o = 0, n = 0xFFFFFFFFu;
+    for (int d = 0; d < 8 * W; ++d) { o |= ta[d] | wp[d]; n &= ta[d] & wp[d]; }
+    uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
+    uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
+    const int np = force_np ? force_np : planes_needed((o8 ^ n8) & 0xFFu);
+    switch (np) {
+    case 5: return run_wide_np<M, 5, W>(ta, la, wp, lb, wbn[0]);
+    case 6: return run_wide_np<M, 6, W>(ta, la, wp, lb, wbn[0]);
+    default: return run_wide_np<M, 7, W>(ta, la, wp, lb, wbn[0]);
+    }
+}
+
+template <int W>
+static double run_wide_m(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
+{
+    switch (measure) {
+    case LEVENSHTEIN: return run_wide<LEVENSHTEIN, W>(a, la, b, lb, force_np, fill);
+    case JARO: return run_wide<JARO, W>(a, la, b, lb, force_np, fill);
+    case JARO_WINKLER: return run_wide<JARO_WINKLER, W>(a, la, b, lb, force_np, fill);
+    case JACCARD: return run_wide<JACCARD, W>(a, la, b, lb, force_np, fill);
+    default: return run_wide<SORENSEN_DICE, W>(a, la, b, lb, force_np, fill);
+    }
+}
+
+// strings of 1..32*W bytes each
+extern "C" double harness_lane_pair_wide(int measure, int W, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb,
+                                         int force_np, int fill)
+{
+    if (W == 1) return run_wide_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 2) return run_wide_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
 }

@@ -93,6 +93,17 @@ def test_wave_path_unicode_and_long(S, ctx, measure):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("lo,hi,alphabet", [(33, 64, gen.ASCII_LOWER), (65, 128, gen.ASCII_LOWER), (1, 128, "ab"),
+                                            (20, 128, "".join(chr(c) for c in range(1, 128)))])
+def test_wide_lane_path_random(S, ctx, measure, lo, hi, alphabet):
+    """33..128-byte ASCII strings: the W = 2 / W = 4 lane kernel (k_lane_wide)."""
+    A, B = gen.pairs(hash((measure, lo, hi)) & 0xFFFF, 6000, alphabet, lo, hi, max_bytes=128)
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    assert ctx.last_wave_rows <= 64 + sum(1 for a, b in zip(A, B) if not a or not b)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
     rng = random.Random(5)

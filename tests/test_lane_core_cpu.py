@@ -22,13 +22,16 @@ CSRC = os.path.join(ROOT, "polars-strsim_amd", "csrc")
 @pytest.fixture(scope="module")
 def harness():
     so = os.path.join(HDIR, "liblane_core_harness.so")
-    srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h")]
+    srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h"),
+            os.path.join(CSRC, "strsim_lane_wide.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
                                "-I", CSRC, "-o", so, srcs[0]])
     L = C.CDLL(so)
     L.harness_lane_pair.restype = C.c_double
     L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
+    L.harness_lane_pair_wide.restype = C.c_double
+    L.harness_lane_pair_wide.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_check_planes.restype = C.c_int
     L.harness_check_planes.argtypes = [C.c_char_p]
     return L
@@ -111,3 +114,30 @@ def test_lane_core_length_boundaries(harness, measure):
                 a = bytes(rng.choice(b"abc") for _ in range(la))
                 b = bytes(rng.choice(b"abc") for _ in range(lb))
                 assert bits(lane(harness, measure, a, b)) == bits(O.pair(measure, a, b)), (a, b)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("W", [1, 2, 4])
+def test_wide_cores_random_bit_exact(harness, measure, W):
+    rng = random.Random(1000 + W)
+    for alphabet in (b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))):
+        for n, (a, b) in enumerate(_rand_pairs(rng, 700, alphabet, maxlen=32 * W)):
+            if not a or not b:
+                continue
+            exp = O.pair(measure, a, b)
+            for force, fill in ((0, alphabet[n % len(alphabet)]), (7, 0)):
+                got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, len(a), b, len(b), force, fill)
+                assert bits(got) == bits(exp), (measure, W, a, b, got, exp)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_wide_cores_length_boundaries(harness, measure):
+    rng = random.Random(3)
+    lens = (1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128)
+    for la in lens:
+        for lb in lens:
+            W = 4 if max(la, lb) > 64 else 2
+            a = bytes(rng.choice(b"abc") for _ in range(la))
+            b = bytes(rng.choice(b"abc") for _ in range(lb))
+            got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, la, b, lb, 0, ord("c"))
+            assert bits(got) == bits(O.pair(measure, a, b)), (W, a, b)
