@@ -508,6 +508,55 @@ __device__ __forceinline__ uint32_t wave_levenshtein(const uint32_t *sA, uint32_
     return result;
 }
 
+// Levenshtein distance of two ASCII strings, block-based bit-parallel DP (Myers 1999 / Hyyro 2003, the
+// published "advanced block" step): lane k owns rows 32k .. 32k+31 of the LONGER string (up to 64 blocks =
+// 2048 bytes) as bit-planes in registers, the SHORTER string (in LDS, one scalar value per char) supplies
+// the columns; block k works on column t-k at step t and hands its bottom-row delta (+1/0/-1) to block
+// k+1 through a one-lane DPP shift.  The pattern is left-aligned to the top of the last block (window
+// that ENDS at the end of the string), so every hand-off and the score row are bit 31.
+// n + B - 1 steps of ~45 VALU for 32*B*n cells.
+__device__ __forceinline__ uint32_t wave_lev_blocks(const uint8_t *__restrict__ valP, uint32_t p0, uint32_t m,
+                                                    uint32_t totalP, const uint32_t *sT, uint32_t n)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t B = (m + 31u) >> 5;
+    const bool mine = lane < B;
+    uint32_t w[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) w[d] = 0u;
+    if (mine) load_window_any<8>(valP, (int64_t)p0 + (int64_t)m - 32 * (int64_t)(B - lane), totalP, w);
+    uint32_t P[7];
+    build_planes<7>(w, P);
+    const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
+    const uint32_t valid = lane == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
+    uint32_t Pv = valid, Mv = ~valid;
+    uint32_t score = m;
+    uint32_t hout = 0u; // bit 0: +1, bit 1: -1
+    const uint32_t T = n + B - 1u;
+    for (uint32_t t = 0; t < T; ++t) {
+        uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        if (lane == 0u) hin = 1u; // row 0 of the DP: D[0][j] - D[0][j-1] = +1
+        const uint32_t j = t - lane;
+        if (mine && j < n) {
+            const uint32_t c = sT[j];
+            uint32_t Eq = eq_mask<7>(P, valid, c, 0);
+            const uint32_t hinP = hin & 1u, hinN = hin >> 1;
+            const uint32_t Xv = Eq | Mv;
+            Eq |= hinN;
+            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            hout = (Ph >> 31) | ((Mh >> 31) << 1);
+            Ph = (Ph << 1) | hinP;
+            Mh = (Mh << 1) | hinN;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+            if (lane == B - 1u) score += (hout & 1u) - (hout >> 1);
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(B - 1u));
+}
+
 // In-place compaction of the flagged entries of s[0..len) to the front; returns how many.
 __device__ __forceinline__ uint32_t wave_compact(uint32_t *s, const uint8_t *flag, uint32_t len)
 {
@@ -615,6 +664,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     __shared__ uint32_t aux[WAVE_CAP + 64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const uint64_t nchunks = (n + 63u) >> 6;
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
 
@@ -659,7 +709,14 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                 const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
                 const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
                 if (MEASURE == LEVENSHTEIN) {
-                    const uint32_t dist = wave_levenshtein(sA, la, sB, lb, aux);
+                    uint32_t dist;
+                    if (!nonascii) {
+                        // rows = the longer string (in registers, from global), columns = the shorter (LDS)
+                        dist = la8 >= lb8 ? wave_lev_blocks(valA, a0, la8, totalA, sB, lb8)
+                                          : wave_lev_blocks(valB, b0, lb8, totalB, sA, la8);
+                    } else {
+                        dist = wave_levenshtein(sA, la, sB, lb, aux);
+                    }
                     r = epilogue_levenshtein(dist, la, lb);
                 } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
                     uint32_t prefix = 0;

@@ -103,6 +103,16 @@ def test_wide_lane_path_random(S, ctx, measure, lo, hi, alphabet):
     assert ctx.last_wave_rows <= 64 + sum(1 for a, b in zip(A, B) if not a or not b)
 
 
+@pytest.mark.parametrize("alphabet", [gen.ASCII_LOWER, "ab", "".join(chr(c) for c in range(1, 128))])
+def test_long_ascii_levenshtein_blocks(S, ctx, alphabet):
+    """129..1024-byte ASCII strings: block-parallel Myers across lanes (wave_lev_blocks)."""
+    A, B = gen.pairs(len(alphabet), 1500, alphabet, 1, 1024, max_bytes=1024)
+    A2, B2 = gen.pairs(len(alphabet) + 1, 500, alphabet, 900, 1024, max_bytes=1024)
+    A, B = A + A2, B + B2
+    got = gpu(S, ctx, "levenshtein", A, B)
+    assert_bit_exact(got, O.batch_strings("levenshtein", A, B, 8), A, B, "levenshtein")
+
+
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
