@@ -90,8 +90,9 @@ STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
  *
  * The call is asynchronous: it returns once the kernels are enqueued on the context's stream.
  * Results are complete after strsim_ctx_synchronize() (or after later work on the same stream for
- * rows whose strings are <= STRSIM_WAVE_PATH_MAX_BYTES; longer rows are finished inside
- * strsim_ctx_synchronize()).
+ * rows whose strings are <= STRSIM_WAVE_PATH_MAX_BYTES; rows with a longer string are finished by a
+ * second pass that strsim_ctx_synchronize() launches).  All buffers of a call must stay valid until
+ * strsim_ctx_synchronize() has returned.
  */
 STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,

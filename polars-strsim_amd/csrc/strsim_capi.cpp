@@ -63,6 +63,10 @@ struct strsim_ctx {
     hipEvent_t ev[RING][3] = {};
     bool slot_pending[RING] = {};
     bool slot_timed[RING] = {};
+    LaunchArgs slot_args[RING] = {}; // what each pending call was launched with (for the long-string pass)
+    int slot_measure[RING] = {};
+    uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
+    size_t huge_ws_cap = 0;
     int head = 0;
     uint64_t last_wave_rows = 0;
     // staging for strsim_pairs_host (grow-only device buffers)
@@ -75,6 +79,26 @@ struct strsim_ctx {
 };
 
 static int ctx_set_device(strsim_ctx *c) { HIP_TRY(hipSetDevice(c->device)); return STRSIM_OK; }
+
+static int ctx_reserve(void **p, size_t *cap, size_t bytes);
+
+// Rows with a string longer than STRSIM_WAVE_PATH_MAX_BYTES: rerun them with the scratch arrays in global memory.
+static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
+{
+    const uint32_t cap = (st.max_len + 63u) & ~63u;
+    const size_t per_wave = 3u * ((size_t)cap + 64u) * sizeof(uint32_t);
+    size_t waves = st.huge_rows < 512u ? st.huge_rows : 512u;
+    const size_t budget = (size_t)4 << 30; // keep the workspace under 4 GiB
+    if (waves * per_wave > budget) waves = budget / per_wave ? budget / per_wave : 1;
+    int rc = ctx_reserve((void **)&c->huge_ws, &c->huge_ws_cap, waves * per_wave);
+    if (rc) return rc;
+    LaunchArgs a = c->slot_args[slot];
+    a.ev_lane0 = a.ev_lane1 = a.ev_wave1 = nullptr;
+    hipError_t e = launch_huge(c->slot_measure[slot], a, c->huge_ws, cap, (int)waves);
+    if (e != hipSuccess) return hip_fail(e, "long-string kernel launch");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return STRSIM_OK;
+}
 
 // Retire every pending slot (the stream must already be synchronised).
 static int ctx_drain(strsim_ctx *c)
@@ -94,18 +118,14 @@ static int ctx_drain(strsim_ctx *c)
         }
         const DevStatus &st = c->status_host[s];
         c->last_wave_rows = st.wave_rows;
-        if (st.huge_rows != 0 && rc == STRSIM_OK) {
-            set_error("%u row(s) hold a string longer than %u bytes (longest: %u bytes); the long-string pass is not "
-                      "available in this build",
-                      st.huge_rows, (unsigned)STRSIM_WAVE_PATH_MAX_BYTES, st.max_len);
-            rc = STRSIM_ERR_INTERNAL;
-        }
+        if (st.huge_rows != 0 && rc == STRSIM_OK) rc = ctx_run_huge(c, s, st);
     }
     return rc;
 }
 
 static int ctx_reserve(void **p, size_t *cap, size_t bytes)
 {
+    using namespace strsim;
     if (bytes <= *cap) return STRSIM_OK;
     if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
@@ -175,6 +195,7 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
             if (c->ev[s][i]) (void)hipEventDestroy(c->ev[s][i]);
     for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
     if (c->slowmask) (void)hipFree(c->slowmask);
+    if (c->huge_ws) (void)hipFree(c->huge_ws);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -246,6 +267,8 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
     hipError_t e = launch_pairs(measure, la);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     c->slot_timed[slot] = c->timing;
+    c->slot_args[slot] = la;
+    c->slot_measure[slot] = measure;
     HIP_TRY(hipMemcpyAsync(c->status_host + slot, c->status + slot, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
     c->slot_pending[slot] = true;
     c->head = (slot + 1) % strsim_ctx::RING;
@@ -288,8 +311,11 @@ int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const
     rc = strsim_pairs_device(c, measure, (const uint32_t *)c->stage[0], (const uint8_t *)c->stage[1], a_rows,
                              (const uint32_t *)c->stage[2], (const uint8_t *)c->stage[3], b_rows, (double *)c->stage[4], n);
     if (rc) return rc;
+    rc = strsim_ctx_synchronize(c); // also runs the long-string pass, which writes into the staged output
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->stage[4], n * 8, hipMemcpyDeviceToHost, c->stream));
-    return strsim_ctx_synchronize(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return STRSIM_OK;
 }
 
 int strsim_ctx_timing_enable(strsim_ctx_t *c, int enable)

@@ -27,4 +27,7 @@ struct LaunchArgs {
 
 hipError_t launch_pairs(int measure, const LaunchArgs &a);
 
+// Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with 3 * (cap + 64) words of `ws`.
+hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid);
+
 } // namespace strsim

@@ -357,7 +357,15 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
     const uint64_t nchunks = (n + 63u) >> 6;
     const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
 
-    for (uint64_t span = blockIdx.x; span < nspans; span += gridDim.x) {
+    // Super-spans of WIDE_BLOCK mask words (one per thread, coalesced): a workgroup-wide OR decides whether
+    // any of its WIDE_BLOCK / WIDE_SPAN spans needs work at all -- the common all-clear case costs one barrier.
+    constexpr int SPANS_PER_SUPER = WIDE_BLOCK / WIDE_SPAN;
+    const uint64_t nsuper = (nspans + SPANS_PER_SUPER - 1) / SPANS_PER_SUPER;
+    for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+      const uint64_t cw = sup * WIDE_BLOCK + tid;
+      const unsigned long long myword = cw < nchunks ? slowmask[cw] : 0ull;
+      if (!__syncthreads_or(myword != 0ull)) continue;
+      for (uint64_t span = sup * SPANS_PER_SUPER; span < (sup + 1) * SPANS_PER_SUPER && span < nspans; ++span) {
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 2u) s_cnt[tid] = 0u;
@@ -410,6 +418,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
             if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
         }
         __syncthreads();
+      }
     }
 }
 
@@ -651,6 +660,52 @@ __device__ __forceinline__ uint32_t wave_multiset_isect(const uint32_t *sA, uint
     return wave_sum(acc);
 }
 
+// One row on one wave: decode both strings to scalar values in sA/sB (capacity >= their byte lengths), run the
+// measure.  aux: >= max(len)+64 words of scratch (DP boundary row / Jaro flags / histograms).  The scratch may
+// be LDS (k_wave_pairs) or global memory (k_huge_pairs): the code is address-space agnostic after inlining.
+template <int MEASURE>
+__device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uint32_t a0, uint32_t la8, uint32_t totalA,
+                                           const uint8_t *__restrict__ valB, uint32_t b0, uint32_t lb8, uint32_t totalB,
+                                           uint32_t *sA, uint32_t *sB, uint32_t *aux, uint32_t cap)
+{
+    const uint32_t lane = lane_id();
+    if (la8 == 0u && lb8 == 0u) return 1.0;
+    if (la8 == 0u || lb8 == 0u) return 0.0; // also Levenshtein: 1 - max/max
+    bool nonascii = false;
+    __syncthreads();
+    const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
+    const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
+    double r;
+    if (MEASURE == LEVENSHTEIN) {
+        uint32_t dist;
+        const uint32_t longer = la8 > lb8 ? la8 : lb8;
+        if (!nonascii && longer <= 2048u) {
+            // rows = the longer string (in registers, from global), columns = the shorter (scratch)
+            dist = la8 >= lb8 ? wave_lev_blocks(valA, a0, la8, totalA, sB, lb8)
+                              : wave_lev_blocks(valB, b0, lb8, totalB, sA, la8);
+        } else {
+            dist = wave_levenshtein(sA, la, sB, lb, aux);
+        }
+        r = epilogue_levenshtein(dist, la, lb);
+    } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        uint32_t prefix = 0;
+        if (MEASURE == JARO_WINKLER) {
+            const uint32_t lim = la < lb ? (la < 4u ? la : 4u) : (lb < 4u ? lb : 4u);
+            const unsigned long long ne = __ballot(lane < lim && sA[lane < lim ? lane : 0u] != sB[lane < lim ? lane : 0u]);
+            prefix = ne ? (uint32_t)__builtin_ctzll(ne) : lim;
+        }
+        uint32_t m, t;
+        uint8_t *fl = reinterpret_cast<uint8_t *>(aux);
+        wave_jaro(sA, la, sB, lb, fl, fl + cap, m, t);
+        r = epilogue_jaro(m, t, la, lb);
+        if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, prefix);
+    } else {
+        const uint32_t isect = wave_multiset_isect(sA, la, sB, lb, aux, nonascii);
+        r = MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+    }
+    return r;
+}
+
 template <int MEASURE>
 __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
                                                    uint64_t rowsA, const uint32_t *__restrict__ offB,
@@ -673,77 +728,79 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     // (lane k holds chunk k's word) and visits the non-zero ones.
     const uint64_t nwaves = gridDim.x;
     for (uint64_t kbase = 0; kbase * nwaves < nchunks; kbase += 64u) {
-      const uint64_t cmine = (kbase + lane) * nwaves + blockIdx.x;
-      const unsigned long long mword = cmine < nchunks ? slowmask[cmine] : 0ull;
-      unsigned long long pending = __ballot(mword != 0ull);
-      while (pending != 0ull) {
-        const uint32_t src = (uint32_t)__builtin_ctzll(pending);
-        pending &= pending - 1ull;
-        const uint64_t chunk = (kbase + src) * nwaves + blockIdx.x;
-        unsigned long long mask =
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
-            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
-        while (mask != 0ull) {
-            const uint32_t bitpos = (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const uint64_t row = chunk * 64u + bitpos;
-            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-            const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
-            const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
-            const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
-            ++my_rows;
-            if (la8 > (uint32_t)WAVE_CAP || lb8 > (uint32_t)WAVE_CAP) {
-                ++my_huge; // finished by the host-driven long-string pass (see strsim_capi.cpp)
-                const uint32_t ml = la8 > lb8 ? la8 : lb8;
-                my_maxlen = my_maxlen > ml ? my_maxlen : ml;
-                continue;
-            }
-            double r;
-            if (la8 == 0u && lb8 == 0u) {
-                r = 1.0;
-            } else if (la8 == 0u || lb8 == 0u) {
-                r = 0.0; // also Levenshtein: 1 - max/max
-            } else {
-                bool nonascii = false;
-                __syncthreads();
-                const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
-                const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
-                if (MEASURE == LEVENSHTEIN) {
-                    uint32_t dist;
-                    if (!nonascii) {
-                        // rows = the longer string (in registers, from global), columns = the shorter (LDS)
-                        dist = la8 >= lb8 ? wave_lev_blocks(valA, a0, la8, totalA, sB, lb8)
-                                          : wave_lev_blocks(valB, b0, lb8, totalB, sA, la8);
-                    } else {
-                        dist = wave_levenshtein(sA, la, sB, lb, aux);
-                    }
-                    r = epilogue_levenshtein(dist, la, lb);
-                } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
-                    uint32_t prefix = 0;
-                    if (MEASURE == JARO_WINKLER) {
-                        const uint32_t lim = la < lb ? (la < 4u ? la : 4u) : (lb < 4u ? lb : 4u);
-                        const unsigned long long ne = __ballot(lane < lim && sA[lane < lim ? lane : 0u] != sB[lane < lim ? lane : 0u]);
-                        prefix = ne ? (uint32_t)__builtin_ctzll(ne) : lim;
-                    }
-                    uint32_t m, t;
-                    uint8_t *fl = reinterpret_cast<uint8_t *>(aux);
-                    wave_jaro(sA, la, sB, lb, fl, fl + WAVE_CAP, m, t);
-                    r = epilogue_jaro(m, t, la, lb);
-                    if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, prefix);
-                } else {
-                    const uint32_t isect = wave_multiset_isect(sA, la, sB, lb, aux, nonascii);
-                    r = MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+        const uint64_t cmine = (kbase + lane) * nwaves + blockIdx.x;
+        const unsigned long long mword = cmine < nchunks ? slowmask[cmine] : 0ull;
+        unsigned long long pending = __ballot(mword != 0ull);
+        while (pending != 0ull) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+            pending &= pending - 1ull;
+            const uint64_t chunk = (kbase + src) * nwaves + blockIdx.x;
+            unsigned long long mask =
+                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
+            while (mask != 0ull) {
+                const uint32_t bitpos = (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const uint64_t row = chunk * 64u + bitpos;
+                const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
+                const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
+                const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
+                ++my_rows;
+                if (la8 > (uint32_t)WAVE_CAP || lb8 > (uint32_t)WAVE_CAP) {
+                    ++my_huge; // finished by k_huge_pairs, launched from strsim_ctx_synchronize()
+                    const uint32_t ml = la8 > lb8 ? la8 : lb8;
+                    my_maxlen = my_maxlen > ml ? my_maxlen : ml;
+                    continue;
                 }
+                const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP);
+                if (lane == 0u) out[row] = r;
             }
-            if (lane == 0u) out[row] = r;
         }
-      }
     }
     if (lane == 0u && my_rows != 0u) {
         atomicAdd(&status->wave_rows, my_rows);
         if (my_huge != 0u) {
             atomicAdd(&status->huge_rows, my_huge);
             atomicMax(&status->max_len, my_maxlen);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_huge_pairs: rows with a string longer than WAVE_CAP bytes, same algorithms with the scratch arrays in a
+// global-memory workspace (3 * (cap + 64) words per wave).  Launched only when k_wave_pairs counted such rows.
+// ------------------------------------------------------------------------------------------------
+template <int MEASURE>
+__global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
+                                                   uint64_t rowsA, const uint32_t *__restrict__ offB,
+                                                   const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                   double *__restrict__ out, uint64_t n, uint32_t *__restrict__ ws,
+                                                   uint32_t cap)
+{
+    const uint32_t lane = lane_id();
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
+    uint32_t *sA = ws + (uint64_t)blockIdx.x * 3u * ((uint64_t)cap + 64u);
+    uint32_t *sB = sA + cap + 64u;
+    uint32_t *aux = sB + cap + 64u;
+    for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n; base += (uint64_t)gridDim.x * 64u) {
+        const uint64_t rmine = base + lane;
+        bool big = false;
+        if (rmine < n) {
+            const uint64_t ra = bcastA ? 0 : rmine, rb = bcastB ? 0 : rmine;
+            big = (offA[ra + 1] - offA[ra]) > (uint32_t)WAVE_CAP || (offB[rb + 1] - offB[rb]) > (uint32_t)WAVE_CAP;
+        }
+        unsigned long long pending = __ballot(big);
+        while (pending != 0ull) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+            pending &= pending - 1ull;
+            const uint64_t row = base + src;
+            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+            const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
+            const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
+            const double r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap);
+            if (lane == 0u) out[row] = r;
         }
     }
 }
@@ -763,14 +820,34 @@ static void launch_pair(const LaunchArgs &a)
                        a.valB, a.rowsB, a.out, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
-        const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
-        const uint64_t g3 = nspans < (uint64_t)a.wide_grid ? nspans : (uint64_t)a.wide_grid;
+        const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
+        const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
         hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status);
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
+}
+
+template <int M>
+static void launch_huge_t(const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid)
+{
+    hipLaunchKernelGGL((k_huge_pairs<M>), dim3((unsigned)grid), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, a.out, a.n, ws, cap);
+}
+
+hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid)
+{
+    switch (measure) {
+    case LEVENSHTEIN: launch_huge_t<LEVENSHTEIN>(a, ws, cap, grid); break;
+    case JARO: launch_huge_t<JARO>(a, ws, cap, grid); break;
+    case JARO_WINKLER: launch_huge_t<JARO_WINKLER>(a, ws, cap, grid); break;
+    case JACCARD: launch_huge_t<JACCARD>(a, ws, cap, grid); break;
+    case SORENSEN_DICE: launch_huge_t<SORENSEN_DICE>(a, ws, cap, grid); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_pairs(int measure, const LaunchArgs &a)

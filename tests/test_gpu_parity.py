@@ -145,6 +145,29 @@ def test_literal_broadcast(S, ctx, measure):
         assert_bit_exact(got, O.batch_strings(measure, [lit], B, 4), [lit], B, measure + " lit,col")
 
 
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_strings_beyond_the_wave_kernel_cap(S, ctx, measure):
+    """> 1024-byte strings: finished by the second pass launched from strsim_ctx_synchronize()."""
+    import random
+    rng = random.Random(41)
+    A, B = gen.pairs(31, 300, gen.ASCII_LOWER, 0, 40)
+    specs = [(1025, 1025, gen.ASCII_LOWER), (2048, 1500, "ab"), (2049, 10, gen.ASCII_LOWER), (3000, 2800, gen.ASCII_LOWER),
+             (5, 4000, gen.ASCII_LOWER), (1200, 1100, gen.MIXED), (0, 1500, gen.ASCII_LOWER), (1500, 1500, "a")]
+    for la, lb, alpha in specs:
+        a = "".join(rng.choice(alpha) for _ in range(la))
+        b = gen.edit(rng, a, alpha, 3) if la == lb and la > 0 else "".join(rng.choice(alpha) for _ in range(lb))
+        pos = rng.randrange(len(A))
+        A.insert(pos, a)
+        B.insert(pos, b)
+    A.append(A[10] * 60)  # a == b, long
+    B.append(A[-1])
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    # and the context keeps working afterwards
+    got = gpu(S, ctx, measure, A[:50], B[:50])
+    assert_bit_exact(got, O.batch_strings(measure, A[:50], B[:50]), A[:50], B[:50], measure)
+
+
 def test_shape_mismatch(S, ctx):
     with pytest.raises(S.ShapeMismatch, match="Inputs must have the same length, or one of them must be a Utf8 literal."):
         gpu(S, ctx, "jaro", ["a", "b"], ["a", "b", "c"])
