@@ -87,14 +87,13 @@ def main():
 
     cfg = W.CONFIGS[a.config]
     measure = a.measure or cfg[0]
-    if measure == "all":
-        measure = "levenshtein"
+    measures = list(S.MEASURES) if measure == "all" else [measure]  # cfg4: five passes over the same frame per step
     rows = a.rows or cfg[1]
     _, _, law, lo, hi, seed = cfg
 
     # rank r holds rows [r*rows, (r+1)*rows) of the (world*rows)-row frame
     offA, valA, offB, valB, bytesA, bytesB = W.device_columns(seed, law, lo, hi, rank * rows, rows, dev)
-    out = [torch.empty(rows, dtype=torch.float64, device=dev) for _ in range(2)]
+    out = [torch.empty(rows, dtype=torch.float64, device=dev) for _ in range(2 * len(measures))]
 
     compute_stream = torch.cuda.current_stream()
     ctx = S.Context(local_rank, stream=compute_stream.cuda_stream)
@@ -108,15 +107,16 @@ def main():
     pending = []
 
     def step(i):
-        o = out[i & 1]
-        if gather and len(pending) >= 2:  # the buffer we are about to overwrite must have been sent
-            pending.pop(0).wait()
-        ctx.pairs_device(measure, offA, valA, offB, valB, out=o)
-        if gather:
-            comm_stream.wait_stream(compute_stream)
-            with torch.cuda.stream(comm_stream):
-                work, _ = gather_column(o, world * rows, dst=0, async_op=True, recv_buffer=recv)
-            pending.append(work)
+        for k, m in enumerate(measures):
+            o = out[(i & 1) * len(measures) + k]
+            if gather and len(pending) >= 2 * len(measures):  # the buffer we are about to overwrite must have been sent
+                pending.pop(0).wait()
+            ctx.pairs_device(m, offA, valA, offB, valB, out=o)
+            if gather:
+                comm_stream.wait_stream(compute_stream)
+                with torch.cuda.stream(comm_stream):
+                    work, _ = gather_column(o, world * rows, dst=0, async_op=True, recv_buffer=recv)
+                pending.append(work)
 
     def drain():
         while pending:
@@ -157,9 +157,20 @@ def main():
         write_bytes = 8 * rows
         lane_ms = tm["lane_ms"] / max(tm["lane_launches"], 1)
         wave_ms = tm["wave_ms"] / max(tm["wave_launches"], 1)
+        # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc run of this same command
+        # (bench_support/profile.sh -> profiles/traffic.json; FETCH_SIZE doubled per the gfx950 note)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            key = f"{a.config}:{measures[0]}:{rows}"
+            if len(measures) == 1 and key in tj:
+                traffic = tj[key]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         achieved = read_bytes / (lane_ms * 1e-3) / 1e9 if lane_ms > 0 else 0.0
         res = {
             "metric": "M string-pairs/s, %s, %d M rows/GPU (+ achieved HBM GB/s in roofline)" % (measure, rows // 1_000_000),
+            "passes_per_step": len(measures),
             "value": value, "unit": "M string-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 bit-parallel, f64 epilogue", "data": "synthetic",
@@ -167,17 +178,17 @@ def main():
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
                        "rows_per_gpu": rows, "gather_f64_to_rank0": bool(gather),
                        "rows_on_wave_kernel": wave_rows},
-            "roofline": {"bound": "hbm", "kernel": "k_lane_pairs<%s>" % measure, "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_lane_pairs<%s>" % measures[0], "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_read_bytes": read_bytes, "algorithmic_write_bytes": write_bytes,
                          "kernel_ms": lane_ms, "wave_kernel_ms": wave_ms,
                          "achieved_read_plus_write": (read_bytes + write_bytes) / (lane_ms * 1e-3) / 1e9 if lane_ms > 0 else 0.0},
         }
         if not a.no_cpu_baseline:
             try:
-                cb, (n_s, exp) = cpu_baseline(measure, cfg, rows)
+                cb, (n_s, exp) = cpu_baseline(measures[0], cfg, rows)
                 res["cpu_baseline"] = cb
-                got = out[(a.steps - 1) & 1][:n_s].cpu().numpy()
+                got = out[((a.steps - 1) & 1) * len(measures)][:n_s].cpu().numpy()
                 import numpy as np
                 res["parity_vs_oracle_on_sample"] = {"rows": int(n_s), "bit_mismatches": int((got.view(np.uint64) != exp.view(np.uint64)).sum())}
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
