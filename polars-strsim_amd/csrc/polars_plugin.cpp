@@ -4,9 +4,11 @@
 //
 // What happens per call (one Polars expression evaluation):
 //   1. both input Series (any chunking; Arrow "vu" string views as Polars >= 0.20 sends them, or "u"/"U"
-//      offset layouts) are flattened into the device layout: offsets + packed UTF-8 values (+ validity);
-//   2. shape rule and literal broadcast exactly as strsim.rs:48-52,61-66;
-//   3. rows go to the GPU in batches whose packed values fit 32-bit offsets (strsim_pairs_host);
+//      offset layouts) are described in place; shape rule and literal broadcast exactly as strsim.rs:48-52,61-66;
+//   2. rows are cut into slices of 2 M rows; each slice is packed by helper threads (none when the engine says it
+//      is already parallel, strsim.rs:53) into the device layout -- uint32 offsets + packed UTF-8 values -- in pinned
+//      staging memory;
+//   3. a two-slot software pipeline overlaps packing slice k+1 with H2D + kernels of slice k (strsim_pairs_device);
 //   4. the f64 column comes back as one Arrow "g" chunk whose validity is the AND of the inputs'
 //      validities (null in -> null out, README.md:69-70); values under null slots are computed like the
 //      reference's arity helpers do and are never observable.
@@ -22,7 +24,15 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
+
+#include <hip/hip_runtime.h>
 
 #include "polars_plugin_abi.h"
 #include "strsim_amd.h"
@@ -38,12 +48,20 @@ struct PluginError {
 
 [[noreturn]] void fail(const std::string &m) { throw PluginError{m}; }
 
-// ---- one input Series, flattened -----------------------------------------------------------------
-struct FlatColumn {
-    std::vector<uint64_t> offsets; // rows + 1
-    std::vector<uint8_t> values;
-    std::vector<uint8_t> valid;    // one byte per row; empty = no nulls
+// ---- one input Series, described (no copy) --------------------------------------------------------
+struct Chunk {
+    const ArrowArray *a;
+    uint64_t row0;         // first row of this chunk within the Series
+    const uint8_t *nulls;  // validity bitmap if the chunk has nulls, else nullptr
+};
+
+enum Layout { L_VIEW, L_U32, L_U64 };
+
+struct Column {
+    Layout layout = L_VIEW;
+    std::vector<Chunk> chunks; // non-empty chunks only
     uint64_t rows = 0;
+    bool any_null = false;
     std::string name;
 };
 
@@ -54,87 +72,109 @@ struct View { // Arrow BinaryView / Utf8View element
     uint8_t rest[12]; // <= 12 bytes inline, else {prefix[4], buffer_index u32, offset u32}
 };
 
-void flatten(const SeriesExport &s, FlatColumn &out)
+void describe(const SeriesExport &s, Column &c)
 {
     if (!s.field || !s.field->format) fail("input series has no schema");
     const std::string fmt = s.field->format;
-    const bool is_view = fmt == "vu", is_u = fmt == "u", is_U = fmt == "U";
-    if (!is_view && !is_u && !is_U)
-        fail("invalid series dtype: expected `String`, got Arrow format `" + fmt + "`"); // `.str()?`, strsim.rs:46-47
-    out.name = s.field->name ? s.field->name : "";
-    uint64_t rows = 0, bytes = 0;
-    bool any_null = false;
-    // pass 1: sizes
-    for (size_t c = 0; c < s.len; ++c) {
-        const ArrowArray *a = s.arrays[c];
+    if (fmt == "vu") c.layout = L_VIEW;
+    else if (fmt == "u") c.layout = L_U32;
+    else if (fmt == "U") c.layout = L_U64;
+    else fail("invalid series dtype: expected `String`, got Arrow format `" + fmt + "`"); // `.str()?`, strsim.rs:46-47
+    c.name = s.field->name ? s.field->name : "";
+    for (size_t k = 0; k < s.len; ++k) {
+        const ArrowArray *a = s.arrays[k];
         if (!a) fail("null chunk pointer");
         if (a->length < 0 || a->offset < 0) fail("negative length/offset in chunk");
-        const uint8_t *vb = a->n_buffers > 0 ? static_cast<const uint8_t *>(a->buffers[0]) : nullptr;
-        if (a->null_count != 0 && vb) any_null = true;
-        rows += (uint64_t)a->length;
         if (a->length == 0) continue;
-        if (is_view) {
-            if (a->n_buffers < 2) fail("Utf8View chunk without a views buffer");
-            const View *v = static_cast<const View *>(a->buffers[1]) + a->offset;
-            for (int64_t i = 0; i < a->length; ++i)
-                if (!vb || bit_at(vb, a->offset + i)) bytes += v[i].len;
-        } else if (is_u) {
-            if (a->n_buffers < 3) fail("Utf8 chunk without offsets/values buffers");
-            const int32_t *o = static_cast<const int32_t *>(a->buffers[1]) + a->offset;
-            bytes += (uint64_t)(o[a->length] - o[0]);
+        if (c.layout == L_VIEW ? a->n_buffers < 2 : a->n_buffers < 3) fail("string chunk is missing buffers");
+        const uint8_t *vb = (a->null_count != 0 && a->n_buffers > 0) ? static_cast<const uint8_t *>(a->buffers[0]) : nullptr;
+        if (vb) c.any_null = true;
+        c.chunks.push_back(Chunk{a, c.rows, vb});
+        c.rows += (uint64_t)a->length;
+    }
+}
+
+// first chunk containing row r (r < rows)
+inline size_t chunk_of(const Column &c, uint64_t r)
+{
+    size_t lo = 0, hi = c.chunks.size() - 1;
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        if (c.chunks[mid].row0 <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+inline bool row_valid(const Column &c, uint64_t r)
+{
+    if (!c.any_null) return true;
+    const Chunk &k = c.chunks[chunk_of(c, r)];
+    return !k.nulls || bit_at(k.nulls, k.a->offset + (int64_t)(r - k.row0));
+}
+
+// packed byte count of rows [r0, r1); a null view slot counts as empty
+uint64_t range_bytes(const Column &c, uint64_t r0, uint64_t r1)
+{
+    uint64_t bytes = 0;
+    for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
+        const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)k.a->length) - k.row0);
+        if (c.layout == L_VIEW) {
+            const View *v = static_cast<const View *>(k.a->buffers[1]) + k.a->offset;
+            if (!k.nulls) for (int64_t i = i0; i < i1; ++i) bytes += v[i].len;
+            else for (int64_t i = i0; i < i1; ++i) if (bit_at(k.nulls, k.a->offset + i)) bytes += v[i].len;
+        } else if (c.layout == L_U32) {
+            const int32_t *o = static_cast<const int32_t *>(k.a->buffers[1]) + k.a->offset;
+            bytes += (uint64_t)(o[i1] - o[i0]);
         } else {
-            if (a->n_buffers < 3) fail("LargeUtf8 chunk without offsets/values buffers");
-            const int64_t *o = static_cast<const int64_t *>(a->buffers[1]) + a->offset;
-            bytes += (uint64_t)(o[a->length] - o[0]);
+            const int64_t *o = static_cast<const int64_t *>(k.a->buffers[1]) + k.a->offset;
+            bytes += (uint64_t)(o[i1] - o[i0]);
         }
     }
-    out.rows = rows;
-    out.offsets.resize(rows + 1);
-    out.values.resize(bytes + 64); // slack so device staging never reads past the vector
-    if (any_null) out.valid.assign(rows, 1);
-    // pass 2: copy
-    uint64_t r = 0, pos = 0;
-    out.offsets[0] = 0;
-    for (size_t c = 0; c < s.len; ++c) {
-        const ArrowArray *a = s.arrays[c];
-        if (a->length == 0) continue;
-        const uint8_t *vb = (a->null_count != 0 && a->n_buffers > 0) ? static_cast<const uint8_t *>(a->buffers[0]) : nullptr;
-        if (is_view) {
+    return bytes;
+}
+
+// pack rows [r0, r1): off[i - r0 + 1] = end of row i (starting from `base`), bytes appended at val + base;
+// `limit` = end of this range's bytes (another thread owns what follows)
+void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64_t base, uint64_t limit, uint8_t *val)
+{
+    uint64_t pos = base;
+    uint32_t *o_out = off + 1;
+    for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        const ArrowArray *a = k.a;
+        const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
+        const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)a->length) - k.row0);
+        if (c.layout == L_VIEW) {
             const View *v = static_cast<const View *>(a->buffers[1]) + a->offset;
-            for (int64_t i = 0; i < a->length; ++i, ++r) {
-                const bool ok = !vb || bit_at(vb, a->offset + i);
-                if (ok) {
+            for (int64_t i = i0; i < i1; ++i) {
+                if (!k.nulls || bit_at(k.nulls, a->offset + i)) {
                     const uint32_t len = v[i].len;
-                    const uint8_t *src;
                     if (len <= 12) {
-                        src = v[i].rest;
+                        if (pos + 12 <= limit) memcpy(val + pos, v[i].rest, 12); // fixed-size copy, trimmed by the next row
+                        else memcpy(val + pos, v[i].rest, len);
                     } else {
                         uint32_t bi, bo;
                         memcpy(&bi, v[i].rest + 4, 4);
                         memcpy(&bo, v[i].rest + 8, 4);
                         if ((int64_t)bi + 2 >= a->n_buffers) fail("Utf8View buffer index out of range");
-                        src = static_cast<const uint8_t *>(a->buffers[2 + bi]) + bo;
+                        memcpy(val + pos, static_cast<const uint8_t *>(a->buffers[2 + bi]) + bo, len);
                     }
-                    memcpy(out.values.data() + pos, src, len);
                     pos += len;
-                } else {
-                    out.valid[r] = 0; // a null slot contributes an empty string; its result is masked anyway
                 }
-                out.offsets[r + 1] = pos;
+                *o_out++ = (uint32_t)pos;
             }
         } else {
             const uint8_t *data = static_cast<const uint8_t *>(a->buffers[2]);
-            auto copy_rows = [&](auto *o) {
-                const uint64_t base = (uint64_t)o[0], span = (uint64_t)(o[a->length] - o[0]);
-                if (span) memcpy(out.values.data() + pos, data + base, span);
-                for (int64_t i = 0; i < a->length; ++i, ++r) {
-                    out.offsets[r + 1] = pos + ((uint64_t)o[i + 1] - base);
-                    if (vb && !bit_at(vb, a->offset + i)) out.valid[r] = 0;
-                }
+            auto rows = [&](auto *o) {
+                const uint64_t b0 = (uint64_t)o[i0], span = (uint64_t)(o[i1] - o[i0]);
+                if (span) memcpy(val + pos, data + b0, span);
+                for (int64_t i = i0; i < i1; ++i) *o_out++ = (uint32_t)(pos + ((uint64_t)o[i + 1] - b0));
                 pos += span;
             };
-            if (is_u) copy_rows(static_cast<const int32_t *>(a->buffers[1]) + a->offset);
-            else copy_rows(static_cast<const int64_t *>(a->buffers[1]) + a->offset);
+            if (c.layout == L_U32) rows(static_cast<const int32_t *>(a->buffers[1]) + a->offset);
+            else rows(static_cast<const int64_t *>(a->buffers[1]) + a->offset);
         }
     }
 }
@@ -232,52 +272,129 @@ void *alloc64(size_t bytes)
     return p;
 }
 
+// ---- a tiny fork-join helper for the host-side packing ------------------------------------------------
+void fork_join(unsigned nthreads, const std::function<void(unsigned)> &fn)
+{
+    if (nthreads <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> errs(nthreads);
+    th.reserve(nthreads - 1);
+    auto body = [&](unsigned t) {
+        try { fn(t); } catch (const PluginError &e) { errs[t] = e.msg; } catch (...) { errs[t] = "unexpected failure in a packing thread"; }
+    };
+    for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(body, t);
+    body(0);
+    for (auto &x : th) x.join();
+    for (auto &e : errs) if (!e.empty()) fail(e);
+}
+
+#define HIP_OR_FAIL(expr)                                                                           \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) fail(std::string("HIP error in " #expr ": ") + hipGetErrorString(e__)); \
+    } while (0)
+
+// grow-only buffer: pinned host memory or device memory
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool device = false;
+    void reserve(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        release();
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (device) HIP_OR_FAIL(hipMalloc(&p, want)); else HIP_OR_FAIL(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    void release()
+    {
+        if (p) { if (device) (void)hipFree(p); else (void)hipHostFree(p); }
+        p = nullptr; cap = 0;
+    }
+};
+
+// one pipeline slot: a slice of both columns packed in pinned memory + its device mirror + its results
+struct Slot {
+    Buf h_off[2], h_val[2], h_out, d_off[2], d_val[2], d_out;
+    uint64_t r0 = 0, rows = 0;
+    uint64_t bytes[2] = {0, 0};
+    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; } d_out.device = true; }
+    void release() { for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); } h_out.release(); d_out.release(); }
+};
+
 // ---- device context per calling thread (Polars may call from several of its threads at once) -------
 struct ThreadCtx {
     strsim_ctx_t *ctx = nullptr;
-    ~ThreadCtx() { if (ctx) strsim_ctx_destroy(ctx); }
+    int device = 0;
+    Slot slot[2];
+    Buf lit_off, lit_val; // device copy of a literal side
+    ~ThreadCtx()
+    {
+        if (ctx) {
+            (void)hipSetDevice(device);
+            for (auto &s : slot) s.release();
+            lit_off.release(); lit_val.release();
+            strsim_ctx_destroy(ctx);
+        }
+    }
     strsim_ctx_t *get()
     {
         if (!ctx) {
-            int dev = 0;
-            if (const char *e = getenv("POLARS_STRSIM_DEVICE")) dev = atoi(e);
-            if (strsim_ctx_create(dev, nullptr, &ctx) != STRSIM_OK) fail(strsim_last_error_message());
+            if (const char *e = getenv("POLARS_STRSIM_DEVICE")) device = atoi(e);
+            if (strsim_ctx_create(device, nullptr, &ctx) != STRSIM_OK) fail(strsim_last_error_message());
+            lit_off.device = lit_val.device = true;
         }
+        HIP_OR_FAIL(hipSetDevice(device));
         return ctx;
     }
 };
 thread_local ThreadCtx g_ctx;
 
-constexpr uint64_t BATCH_BYTES = (1ull << 32) - (1ull << 20); // packed values per device batch (u32 offsets)
-constexpr uint64_t BATCH_ROWS = 1ull << 30;
+constexpr uint64_t SLICE_ROWS = 2u << 20;                      // rows packed / shipped / computed per pipeline step
+constexpr uint64_t SLICE_BYTES = (1ull << 32) - (1ull << 24);  // packed values per slice and column (u32 offsets)
 
-// rows [r0, r1) of a flattened column as a u32-offset shard
-struct Shard {
-    std::vector<uint32_t> off;
-    const uint8_t *val;
-    uint64_t rows;
-};
-
-void make_shard(const FlatColumn &c, uint64_t r0, uint64_t r1, Shard &s)
+unsigned pack_threads(bool engine_parallel, uint64_t rows)
 {
-    const uint64_t base = c.offsets[r0];
-    s.rows = r1 - r0;
-    s.off.resize(s.rows + 1);
-    for (uint64_t i = 0; i <= s.rows; ++i) s.off[i] = (uint32_t)(c.offsets[r0 + i] - base);
-    s.val = c.values.data() + base;
+    // CallerContext PARALLEL (reference strsim.rs:53): the engine is already parallel -> no helper threads here
+    if (engine_parallel || rows < 200000) return 1;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) hw = (unsigned)atoi(e);
+    if (hw == 0) hw = 1;
+    return std::min<unsigned>(hw, 32u);
 }
 
-void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret)
+// pack rows [r0, r1) of `c` into pinned staging (u32 offsets rebased to 0); returns the packed byte count
+uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &val, unsigned T)
+{
+    const uint64_t rows = r1 - r0;
+    T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(rows / 65536, 1));
+    std::vector<uint64_t> part(T + 1, 0);
+    auto lo = [&](unsigned t) { return r0 + rows * t / T; };
+    fork_join(T, [&](unsigned t) { part[t + 1] = range_bytes(c, lo(t), lo(t + 1)); });
+    for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
+    const uint64_t total = part[T];
+    if (total > SLICE_BYTES) return total;
+    off.reserve((rows + 1) * sizeof(uint32_t));
+    val.reserve(total + 64);
+    uint32_t *o = static_cast<uint32_t *>(off.p);
+    o[0] = 0;
+    fork_join(T, [&](unsigned t) { pack_range(c, lo(t), lo(t + 1), o + (lo(t) - r0), part[t], part[t + 1], static_cast<uint8_t *>(val.p)); });
+    return total;
+}
+
+void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)
 {
     if (n_inputs != 2) fail("expected 2 input series, got " + std::to_string(n_inputs));
-    FlatColumn a, b;
-    flatten(inputs[0], a);
-    flatten(inputs[1], b);
+    Column col[2];
+    describe(inputs[0], col[0]);
+    describe(inputs[1], col[1]);
+    const Column &a = col[0], &b = col[1];
     // strsim.rs:48-52
     if (a.rows != b.rows && a.rows != 1 && b.rows != 1)
         fail("Inputs must have the same length, or one of them must be a Utf8 literal.");
-    const bool lit_a = a.rows == 1 && b.rows != 1, lit_b = b.rows == 1;
-    const uint64_t n = lit_a ? b.rows : a.rows;
+    const bool lit[2] = {a.rows == 1 && b.rows != 1, b.rows == 1};
+    const uint64_t n = lit[0] ? b.rows : a.rows;
 
     double *out = static_cast<double *>(alloc64(n * sizeof(double)));
     uint8_t *validity = nullptr;
@@ -288,52 +405,112 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret)
     } cleanup{out, validity};
 
     // a NULL literal: the reference unwrap()s and panics (strsim.rs:62,65,87,90); here every row is null
-    const bool a_null_lit = lit_a && !a.valid.empty() && !a.valid[0];
-    const bool b_null_lit = lit_b && !b.valid.empty() && !b.valid[0];
-    const bool all_null = a_null_lit || b_null_lit;
+    const bool all_null = (lit[0] && !row_valid(a, 0)) || (lit[1] && !row_valid(b, 0));
 
     if (n != 0 && !all_null) {
         strsim_ctx_t *ctx = g_ctx.get();
-        Shard sa, sb;
-        if (lit_a) make_shard(a, 0, 1, sa);
-        if (lit_b) make_shard(b, 0, 1, sb);
-        uint64_t r0 = 0;
-        while (r0 < n) {
-            // largest batch whose packed values fit 32-bit offsets on both sides
-            uint64_t r1 = n;
-            if (r1 - r0 > BATCH_ROWS) r1 = r0 + BATCH_ROWS;
-            auto fit = [&](const FlatColumn &c, bool lit) {
-                if (lit) return;
-                if (c.offsets[r1] - c.offsets[r0] <= BATCH_BYTES) return;
-                uint64_t lo = r0 + 1, hi = r1; // first r1 that overflows is > lo
-                while (lo < hi) {
-                    const uint64_t mid = lo + (hi - lo + 1) / 2;
-                    if (c.offsets[mid] - c.offsets[r0] <= BATCH_BYTES) lo = mid; else hi = mid - 1;
-                }
-                r1 = lo;
-            };
-            fit(a, lit_a);
-            fit(b, lit_b);
-            if (r1 == r0) fail("a single string exceeds the 4 GiB batch limit");
-            if (!lit_a) make_shard(a, r0, r1, sa);
-            if (!lit_b) make_shard(b, r0, r1, sb);
-            const int rc = strsim_pairs_host(ctx, measure, sa.off.data(), sa.val, sa.rows, sb.off.data(), sb.val, sb.rows,
-                                             out + r0, r1 - r0);
-            if (rc != STRSIM_OK) fail(strsim_last_error_message());
-            r0 = r1;
+        hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
+        const unsigned T = pack_threads(engine_parallel, n);
+
+        // a literal side is packed and shipped once
+        const uint32_t *lit_off_d = nullptr;
+        const uint8_t *lit_val_d = nullptr;
+        for (int s = 0; s < 2; ++s) {
+            if (!lit[s]) continue;
+            Buf ho, hv;
+            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1);
+            if (bytes > SLICE_BYTES) { ho.release(); hv.release(); fail("a single string exceeds the 4 GiB limit"); }
+            g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
+            g_ctx.lit_val.reserve(bytes + 64);
+            hipError_t e1 = hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            hipError_t e2 = bytes ? hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream) : hipSuccess;
+            hipError_t e3 = hipStreamSynchronize(stream);
+            ho.release(); hv.release();
+            HIP_OR_FAIL(e1); HIP_OR_FAIL(e2); HIP_OR_FAIL(e3);
+            lit_off_d = static_cast<const uint32_t *>(g_ctx.lit_off.p);
+            lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
         }
+
+        // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
+        auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
+            uint64_t rows = std::min<uint64_t>(want, n - r0);
+            for (;;) {
+                bool fits = true;
+                for (int s = 0; s < 2 && fits; ++s) {
+                    if (lit[s]) continue;
+                    sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
+                    fits = sl.bytes[s] <= SLICE_BYTES;
+                }
+                if (fits) break;
+                if (rows == 1) fail("a single string exceeds the 4 GiB limit");
+                rows = (rows + 1) / 2; // very long strings: halve the slice until its packed values fit 32-bit offsets
+            }
+            sl.r0 = r0; sl.rows = rows;
+            return rows;
+        };
+        auto launch = [&](Slot &sl) {
+            const uint32_t *doff[2];
+            const uint8_t *dval[2];
+            uint64_t drows[2];
+            for (int s = 0; s < 2; ++s) {
+                if (lit[s]) { doff[s] = lit_off_d; dval[s] = lit_val_d; drows[s] = 1; continue; }
+                sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
+                sl.d_val[s].reserve(sl.bytes[s] + 64);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
+                doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
+                dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
+                drows[s] = sl.rows;
+            }
+            sl.d_out.reserve(sl.rows * sizeof(double));
+            sl.h_out.reserve(sl.rows * sizeof(double));
+            if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1],
+                                    static_cast<double *>(sl.d_out.p), sl.rows) != STRSIM_OK)
+                fail(strsim_last_error_message());
+        };
+        auto finish = [&](Slot &sl) {
+            if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_OR_FAIL(hipStreamSynchronize(stream));
+            const double *src = static_cast<const double *>(sl.h_out.p);
+            const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
+            fork_join(Tc, [&](unsigned t) {
+                const uint64_t i0 = sl.rows * t / Tc, i1 = sl.rows * (t + 1) / Tc;
+                memcpy(out + sl.r0 + i0, src + i0, (i1 - i0) * sizeof(double));
+            });
+        };
+
+        uint64_t r0 = 0;
+        int cur = 0;
+        r0 += pack(g_ctx.slot[cur], r0, SLICE_ROWS);
+        launch(g_ctx.slot[cur]);
+        while (r0 < n) {
+            const int nxt = cur ^ 1;
+            r0 += pack(g_ctx.slot[nxt], r0, SLICE_ROWS); // overlaps the GPU work of slot `cur`
+            finish(g_ctx.slot[cur]);
+            launch(g_ctx.slot[nxt]);
+            cur = nxt;
+        }
+        finish(g_ctx.slot[cur]);
     }
 
     // output validity = AND of the input validities (broadcast for a literal)
-    const bool need_validity = all_null || !a.valid.empty() || !b.valid.empty();
+    const bool need_validity = all_null || a.any_null || b.any_null;
     if (need_validity && n != 0) {
         validity = static_cast<uint8_t *>(alloc64((n + 7) / 8));
         memset(validity, 0, (n + 7) / 8);
+        // walk both columns chunk by chunk (no per-row binary search)
+        std::vector<uint8_t> ok(n, all_null ? 0 : 1);
+        for (int s = 0; s < 2 && !all_null; ++s) {
+            if (!col[s].any_null) continue;
+            if (lit[s]) continue; // a null literal is the all_null case above
+            for (const Chunk &k : col[s].chunks)
+                if (k.nulls)
+                    for (int64_t i = 0; i < k.a->length; ++i)
+                        if (!bit_at(k.nulls, k.a->offset + i)) ok[k.row0 + (uint64_t)i] = 0;
+        }
         for (uint64_t i = 0; i < n; ++i) {
-            bool ok = !all_null;
-            if (ok && !a.valid.empty()) ok = a.valid[lit_a ? 0 : i] != 0;
-            if (ok && !b.valid.empty()) ok = b.valid[lit_b ? 0 : i] != 0;
-            if (ok) validity[i >> 3] |= (uint8_t)(1u << (i & 7));
+            if (ok[i]) validity[i >> 3] |= (uint8_t)(1u << (i & 7));
             else { ++null_count; out[i] = 0.0; }
         }
     }
@@ -362,11 +539,11 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret)
     ret->private_data = sp;
 }
 
-void plugin_entry(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret)
+void plugin_entry(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, const CallerContext *cc)
 {
     InputGuard guard{inputs, n_inputs};
     try {
-        run(measure, inputs, n_inputs, ret);
+        run(measure, inputs, n_inputs, ret, cc && (cc->bitflags & 1u));
     } catch (const PluginError &e) {
         g_plugin_error = e.msg;
     } catch (const std::bad_alloc &) {
@@ -395,9 +572,9 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_error.
 
 #define POLARS_PLUGIN_DEFINE(name, id)                                                                          \
     void _polars_plugin_##name(SeriesExport *inputs, size_t n_inputs, const uint8_t *, size_t,                  \
-                               SeriesExport *return_value, CallerContext *)                                     \
+                               SeriesExport *return_value, CallerContext *cc)                                   \
     {                                                                                                           \
-        plugin_entry(id, inputs, n_inputs, return_value);                                                       \
+        plugin_entry(id, inputs, n_inputs, return_value, cc);                                                   \
     }                                                                                                           \
     void _polars_plugin_field_##name(ArrowSchema *input_fields, size_t n_fields, ArrowSchema *return_value)     \
     {                                                                                                           \
