@@ -517,37 +517,51 @@ __device__ __forceinline__ uint32_t wave_levenshtein(const uint32_t *sA, uint32_
     return result;
 }
 
-// Levenshtein distance of two ASCII strings, block-based bit-parallel DP (Myers 1999 / Hyyro 2003, the
-// published "advanced block" step): lane k owns rows 32k .. 32k+31 of the LONGER string (up to 64 blocks =
-// 2048 bytes) as bit-planes in registers, the SHORTER string (in LDS, one scalar value per char) supplies
-// the columns; block k works on column t-k at step t and hands its bottom-row delta (+1/0/-1) to block
-// k+1 through a one-lane DPP shift.  The pattern is left-aligned to the top of the last block (window
-// that ENDS at the end of the string), so every hand-off and the score row are bit 31.
-// n + B - 1 steps of ~45 VALU for 32*B*n cells.
-__device__ __forceinline__ uint32_t wave_lev_blocks(const uint8_t *__restrict__ valP, uint32_t p0, uint32_t m,
-                                                    uint32_t totalP, const uint32_t *sT, uint32_t n)
+// Levenshtein distance of ASCII strings, block-based bit-parallel DP (Myers 1999 / Hyyro 2003, the published
+// "advanced block" step), TWO pairs per wave: lanes 0-31 work on job 0, lanes 32-63 on job 1.  Within a job,
+// lane k owns rows 32k .. 32k+31 of the LONGER string (<= 32 blocks = 1024 bytes) as bit-planes in registers,
+// the SHORTER string (bytes in LDS) supplies the columns; block k works on column t-k at step t and hands its
+// bottom-row delta (+1/0/-1) to block k+1 through a one-lane DPP shift.  The pattern is left-aligned to the
+// top of its last block (window that ENDS at the end of the string), so every hand-off and the score row are
+// bit 31.  max(n + B - 1) steps of ~45 VALU for 32*B*n cells per job.
+struct BlockJob {
+    const uint8_t *valP; // column holding the longer string
+    uint32_t p0, m, totalP; // its byte offset / length, and the column's total bytes
+    uint32_t n;          // length of the shorter string (staged in LDS)
+};
+
+__device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const BlockJob &j1, const uint8_t *txt0,
+                                                 const uint8_t *txt1, uint32_t &dist0, uint32_t &dist1)
 {
     const uint32_t lane = lane_id();
-    const uint32_t B = (m + 31u) >> 5;
-    const bool mine = lane < B;
+    const bool hi = lane >= 32u;
+    const uint32_t blk = lane & 31u;
+    const uint8_t *valP = hi ? j1.valP : j0.valP;
+    const uint32_t p0 = hi ? j1.p0 : j0.p0, m = hi ? j1.m : j0.m, totalP = hi ? j1.totalP : j0.totalP;
+    const uint32_t n = hi ? j1.n : j0.n;
+    const uint8_t *txt = hi ? txt1 : txt0;
+    const uint32_t B = (m + 31u) >> 5; // 0 for an empty job
+    const bool mine = blk < B;
     uint32_t w[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) w[d] = 0u;
-    if (mine) load_window_any<8>(valP, (int64_t)p0 + (int64_t)m - 32 * (int64_t)(B - lane), totalP, w);
+    if (mine) load_window_any<8>(valP, (int64_t)p0 + (int64_t)m - 32 * (int64_t)(B - blk), totalP, w);
     uint32_t P[7];
     build_planes<7>(w, P);
     const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
-    const uint32_t valid = lane == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
+    const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
     uint32_t score = m;
     uint32_t hout = 0u; // bit 0: +1, bit 1: -1
-    const uint32_t T = n + B - 1u;
+    const uint32_t T0 = j0.m ? j0.n + ((j0.m + 31u) >> 5) - 1u : 0u;
+    const uint32_t T1 = j1.m ? j1.n + ((j1.m + 31u) >> 5) - 1u : 0u;
+    const uint32_t T = T0 > T1 ? T0 : T1;
     for (uint32_t t = 0; t < T; ++t) {
         uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (lane == 0u) hin = 1u; // row 0 of the DP: D[0][j] - D[0][j-1] = +1
-        const uint32_t j = t - lane;
+        if (blk == 0u) hin = 1u; // row 0 of the DP: D[0][j] - D[0][j-1] = +1
+        const uint32_t j = t - blk;
         if (mine && j < n) {
-            const uint32_t c = sT[j];
+            const uint32_t c = txt[j];
             uint32_t Eq = eq_mask<7>(P, valid, c, 0);
             const uint32_t hinP = hin & 1u, hinN = hin >> 1;
             const uint32_t Xv = Eq | Mv;
@@ -560,10 +574,26 @@ __device__ __forceinline__ uint32_t wave_lev_blocks(const uint8_t *__restrict__ 
             Mh = (Mh << 1) | hinN;
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
-            if (lane == B - 1u) score += (hout & 1u) - (hout >> 1);
+            if (blk == B - 1u) score += (hout & 1u) - (hout >> 1);
         }
     }
-    return (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(B - 1u));
+    const uint32_t B0 = (j0.m + 31u) >> 5, B1 = (j1.m + 31u) >> 5;
+    dist0 = B0 ? (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(B0 - 1u)) : 0u;
+    dist1 = B1 ? (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(32u + B1 - 1u)) : 0u;
+}
+
+// Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
+__device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ p, uint32_t len, uint8_t *dst)
+{
+    const uint32_t lane = lane_id();
+    bool ascii = true;
+    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+        const uint32_t i = c0 + lane;
+        const uint32_t b = i < len ? p[i] : 0u;
+        if (__ballot(b >= 0x80u) != 0ull) ascii = false;
+        if (dst && i < len) dst[i] = (uint8_t)b;
+    }
+    return ascii;
 }
 
 // In-place compaction of the flagged entries of s[0..len) to the front; returns how many.
@@ -677,15 +707,8 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
     const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
     double r;
     if (MEASURE == LEVENSHTEIN) {
-        uint32_t dist;
-        const uint32_t longer = la8 > lb8 ? la8 : lb8;
-        if (!nonascii && longer <= 2048u) {
-            // rows = the longer string (in registers, from global), columns = the shorter (scratch)
-            dist = la8 >= lb8 ? wave_lev_blocks(valA, a0, la8, totalA, sB, lb8)
-                              : wave_lev_blocks(valB, b0, lb8, totalB, sA, la8);
-        } else {
-            dist = wave_levenshtein(sA, la, sB, lb, aux);
-        }
+        // (ASCII rows up to WAVE_CAP bytes never get here: k_wave_pairs runs them two at a time in wave_lev_blocks2)
+        const uint32_t dist = wave_levenshtein(sA, la, sB, lb, aux);
         r = epilogue_levenshtein(dist, la, lb);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t prefix = 0;
@@ -717,11 +740,30 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     __shared__ uint32_t sA[WAVE_CAP];
     __shared__ uint32_t sB[WAVE_CAP];
     __shared__ uint32_t aux[WAVE_CAP + 64];
+    __shared__ uint8_t s_txt8[MEASURE == LEVENSHTEIN ? 2 : 1][MEASURE == LEVENSHTEIN ? WAVE_CAP : 4];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const uint64_t nchunks = (n + 63u) >> 6;
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
+    // Levenshtein on ASCII rows: two rows are collected and run together (one per half wave)
+    BlockJob job[2] = {{nullptr, 0, 0, 0, 0}, {nullptr, 0, 0, 0, 0}};
+    uint64_t job_row[2] = {0, 0};
+    uint32_t job_la[2] = {0, 0}, job_lb[2] = {0, 0};
+    uint32_t njobs = 0;
+    auto flush_jobs = [&]() {
+        if (MEASURE != LEVENSHTEIN || njobs == 0u) return;
+        if (njobs == 1u) job[1] = BlockJob{nullptr, 0, 0, 0, 0};
+        __syncthreads();
+        uint32_t d0, d1;
+        wave_lev_blocks2(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+        if (lane == 0u) {
+            out[job_row[0]] = epilogue_levenshtein(d0, job_la[0], job_lb[0]);
+            if (njobs == 2u) out[job_row[1]] = epilogue_levenshtein(d1, job_la[1], job_lb[1]);
+        }
+        __syncthreads();
+        njobs = 0u;
+    };
 
     // Chunks are dealt round-robin over the waves (chunk = k * nwaves + wave) so that a column full of long rows
     // spreads over the whole chip; each wave fetches the mask words of its next 64 chunks with one load
@@ -753,11 +795,28 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     my_maxlen = my_maxlen > ml ? my_maxlen : ml;
                     continue;
                 }
+                if (MEASURE == LEVENSHTEIN && la8 != 0u && lb8 != 0u) {
+                    // longer string = DP rows (registers, read from global), shorter = columns (LDS bytes)
+                    const bool a_long = la8 >= lb8;
+                    const uint8_t *ps = a_long ? valB + b0 : valA + a0;
+                    const uint32_t ns = a_long ? lb8 : la8;
+                    const bool asc_l = wave_ascii_stage(a_long ? valA + a0 : valB + b0, a_long ? la8 : lb8, nullptr);
+                    const bool asc_s = wave_ascii_stage(ps, ns, s_txt8[njobs & 1u]);
+                    if (asc_l && asc_s) {
+                        job[njobs] = a_long ? BlockJob{valA, a0, la8, totalA, ns} : BlockJob{valB, b0, lb8, totalB, ns};
+                        job_row[njobs] = row;
+                        job_la[njobs] = la8;
+                        job_lb[njobs] = lb8;
+                        if (++njobs == 2u) flush_jobs();
+                        continue;
+                    }
+                }
                 const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP);
                 if (lane == 0u) out[row] = r;
             }
         }
     }
+    flush_jobs();
     if (lane == 0u && my_rows != 0u) {
         atomicAdd(&status->wave_rows, my_rows);
         if (my_huge != 0u) {
