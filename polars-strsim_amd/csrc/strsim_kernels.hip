@@ -346,11 +346,13 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
                                                           unsigned long long *__restrict__ slowmask)
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
-    __shared__ uint32_t s_cnt[2];
-    __shared__ uint16_t s_list[2][WIDE_ROWS];
+    __shared__ uint32_t s_cnt[16];              // rows per key = width class (2) x column-count bucket (8)
+    __shared__ uint16_t s_list[WIDE_ROWS];      // candidate rows (index within the span), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
     __shared__ uint32_t s_fa[WIDE_WAVES][WIDE_MAXW + 1][64];
 
+    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
+    constexpr int RPT = WIDE_ROWS / WIDE_BLOCK; // rows per thread in the collection phase
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
@@ -368,34 +370,53 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
       for (uint64_t span = sup * SPANS_PER_SUPER; span < (sup + 1) * SPANS_PER_SUPER && span < nspans; ++span) {
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
-        if (tid < 2u) s_cnt[tid] = 0u;
+        if (tid < 16u) s_cnt[tid] = 0u;
         __syncthreads();
         const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
-            // ---- collect: rows with 33..128-byte strings on the longer side and a non-empty shorter side
-#pragma unroll 1
-            for (int k = 0; k < WIDE_ROWS / WIDE_BLOCK; ++k) {
+            // ---- collect rows with 33..128-byte strings on the longer side and a non-empty shorter side; key them by
+            //      width class (W = 2 / 4) and by the number of DP columns they will run (the text length)
+            uint32_t key[RPT], rank[RPT];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
                 const uint32_t i = k * WIDE_BLOCK + tid;
+                key[k] = 0xFFFFFFFFu;
                 if ((s_mask[i >> 6] >> (i & 63u)) & 1ull) {
                     const uint64_t row = c0 * 64u + i;
                     const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
                     const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
                     const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
                     if (mx > 32u && mx <= 128u && mn >= 1u) {
+                        const uint32_t steps = SYMMETRIC ? mn : la8;
                         const uint32_t cls = mx > 64u ? 1u : 0u;
-                        s_list[cls][atomicAdd(&s_cnt[cls], 1u)] = (uint16_t)i;
+                        key[k] = cls * 8u + ((steps - 1u) >> (cls ? 4 : 3));
+                        rank[k] = atomicAdd(&s_cnt[key[k]], 1u);
                     }
                 }
             }
             __syncthreads();
-            // ---- rounds of 64 rows, dealt over the waves
-            const uint32_t n2 = s_cnt[0], n4 = s_cnt[1];
-            const uint32_t r2 = (n2 + 63u) >> 6, r4 = (n4 + 63u) >> 6;
-            for (uint32_t r = wv; r < r2 + r4; r += WIDE_WAVES) {
-                const uint32_t cls = r < r2 ? 0u : 1u;
-                const uint32_t li = (cls ? r - r2 : r) * 64u + lane;
-                const bool has = li < (cls ? n4 : n2);
-                const uint32_t i = has ? s_list[cls][li] : 0u;
+            uint32_t total = 0;
+            {
+                uint32_t c[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { c[q] = s_cnt[q]; total += c[q]; }
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    if (key[k] == 0xFFFFFFFFu) continue;
+                    uint32_t base = 0;
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) base += ((uint32_t)q < key[k]) ? c[q] : 0u;
+                    s_list[base + rank[k]] = (uint16_t)(k * WIDE_BLOCK + tid);
+                }
+            }
+            __syncthreads();
+            // ---- rounds of 64 rows of similar width and length, dealt over the waves (longest first)
+            const uint32_t nrounds = (total + 63u) >> 6;
+            for (uint32_t rr = wv; rr < nrounds; rr += WIDE_WAVES) {
+                const uint32_t r = nrounds - 1u - rr;
+                const uint32_t li = r * 64u + lane;
+                const bool has = li < total;
+                const uint32_t i = has ? s_list[li] : 0u;
                 const uint64_t row = c0 * 64u + i;
                 uint32_t a0 = 0, la = 0, b0 = 0, lb = 0;
                 if (has) {
@@ -403,12 +424,17 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
                     a0 = offA[ra]; la = offA[ra + 1] - a0;
                     b0 = offB[rb]; lb = offB[rb + 1] - b0;
                 }
+                const bool swap = SYMMETRIC && la > lb; // symmetric measures walk the shorter string
+                const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
+                const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
+                const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
+                const bool wide4 = __ballot(has && (la > 64u || lb > 64u)) != 0ull;
                 bool done = false;
                 double res = 0.0;
-                if (cls == 0u)
-                    wide_round<MEASURE, 2>(valA, totalA, valB, totalB, has, a0, la, b0, lb, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                if (!wide4)
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
                 else
-                    wide_round<MEASURE, 4>(valA, totalA, valB, totalB, has, a0, la, b0, lb, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
                 if (done) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
