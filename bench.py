@@ -36,6 +36,8 @@ def parse():
     p.add_argument("--measure", default="", help="override the config's measure")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the result shards")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the control flow)")
+    p.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     p.add_argument("--cpu-sample-rows", type=int, default=0)
     return p.parse_args()
 
@@ -79,11 +81,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     cfg = W.CONFIGS[a.config]
     measure = a.measure or cfg[0]
@@ -100,8 +107,9 @@ def main():
     gather = world > 1 and not a.no_gather
     comm_stream = torch.cuda.Stream() if gather else None
     recv = None
+    host_gather = gather and a.backend != "nccl"  # gloo cannot gather device tensors: stage through the host (test mode)
     if gather and rank == 0:
-        recv = torch.empty(world * rows, dtype=torch.float64, device=dev)
+        recv = torch.empty(world * rows, dtype=torch.float64, device="cpu" if host_gather else dev)
     from strsim_amd.distributed import gather_column
 
     pending = []
@@ -115,7 +123,8 @@ def main():
             if gather:
                 comm_stream.wait_stream(compute_stream)
                 with torch.cuda.stream(comm_stream):
-                    work, _ = gather_column(o, world * rows, dst=0, async_op=True, recv_buffer=recv)
+                    src = o.cpu() if host_gather else o
+                    work, _ = gather_column(src, world * rows, dst=0, async_op=True, recv_buffer=recv)
                 pending.append(work)
 
     def drain():
@@ -146,7 +155,7 @@ def main():
     wave_rows = ctx.last_wave_rows
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

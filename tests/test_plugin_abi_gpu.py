@@ -94,3 +94,27 @@ def test_literal_either_side_and_null_cases(H, measure):
     check(H.call_plugin(measure, [None] * 10, [None] * 10), [None] * 10)               # all-null inputs
     check(H.call_plugin(measure, ["x"], ["x"]), [1.0])
     assert H.call_plugin(measure, [], []).to_pylist() == []
+
+
+def test_threaded_packing_and_multi_slice_pipeline(H):
+    """> 2 M rows: several pipeline slices, each packed by helper threads (views with nulls, out-of-line strings)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_support import workload as W
+    n = 4_700_000
+    oa, va, ob, vb = W.host_columns(11, W.UNIFORM, 0, 40, 0, n)
+    a = pa.StringArray.from_buffers(n, pa.py_buffer(oa.astype(np.int32)), pa.py_buffer(va))
+    b = pa.StringArray.from_buffers(n, pa.py_buffer(ob.astype(np.int32)), pa.py_buffer(vb))
+    # nulls in a: every 1000th row
+    mask = np.zeros(n, dtype=bool)
+    mask[::1000] = True
+    a = pa.array(a.to_numpy(zero_copy_only=False), type=pa.string(), mask=mask) if False else pa.StringArray.from_buffers(
+        n, pa.py_buffer(oa.astype(np.int32)), pa.py_buffer(va), pa.py_buffer(np.packbits(~mask, bitorder="little")), int(mask.sum()))
+    exp = O.batch("levenshtein", oa, va, ob, vb, nthreads=8)
+    for layout in ("vu", "u"):
+        got = H.call_plugin("levenshtein", pa.chunked_array([a[:1_000_003], a[1_000_003:]]), b, layout=layout)
+        g = got.to_numpy(zero_copy_only=False)
+        assert got.null_count == int(mask.sum())
+        ok = ~mask
+        assert np.isnan(g[mask]).all()
+        assert (g[ok].view(np.uint64) == exp[ok].view(np.uint64)).all()
