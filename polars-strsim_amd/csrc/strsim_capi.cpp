@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,6 +53,7 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
+    int lane_wg_per_cu = 5; // STRSIM_LANE_WG_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;
     size_t slowmask_cap = 0; // entries
@@ -169,6 +171,10 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipGetDeviceProperties"); }
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *env = getenv("STRSIM_LANE_WG_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 16) c->lane_wg_per_cu = v;
+    }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -255,7 +261,7 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
     la.out = out; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
-    la.lane_grid = c->num_cu * 5;  // 256-thread workgroups; VGPRs admit 5 per CU, the rest of the blocks are grid-strided
+    la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
     la.wave_grid = c->num_cu * 8;
     la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;

@@ -179,33 +179,30 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
         for (int rr = 0; rr < 2; ++rr) {
             const uint32_t r = rr ? (uint32_t)(LANE_ROUNDS - 1) - wv : wv;
             const uint32_t idx = s_perm[r * 64u + lane];
-            const uint32_t a0 = s_a0[idx], b0 = s_b0[idx];
             const uint32_t len = s_len[idx];
-            uint32_t la8 = len & 0xFFFFu, lb8 = len >> 16;
-            uint32_t wa[8], wb[8];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) { wa[d] = 0u; wb[d] = 0u; }
             bool fast = len != 0xFFFFFFFFu;
-            uint32_t vary = 0u;
-            if (fast) {
-                load_window32(valA, a0, totalA, wa);
-                load_window32(valB, b0, totalB, wb);
-                // conservative tests on the whole 32-byte windows (bytes past a string belong to its
-                // neighbours): any high bit sends the row to the code-point kernel; the varying low
-                // bits decide how many bit-planes the match masks need
-                uint32_t any;
-                vary = window_vary(wa, wb, any);
-                if (any & 0x80u) {
-                    fast = false;
-                    atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
-                }
+            uint32_t la8 = fast ? (len & 0xFFFFu) : 0u, lb8 = fast ? (len >> 16) : 0u;
+            // symmetric measures walk the shorter string: pick the roles BEFORE loading (no register swap);
+            // rows this kernel skips read a harmless window at offset 0
+            const bool swap = SYMMETRIC && la8 > lb8;
+            const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
+            const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
+            uint32_t t0 = swap ? s_b0[idx] : s_a0[idx], p0 = swap ? s_a0[idx] : s_b0[idx];
+            if (!fast) { t0 = 0u; p0 = 0u; }
+            if (swap) { const uint32_t t = la8; la8 = lb8; lb8 = t; }
+            uint32_t wa[8], wb[8];
+            load_window32(vT, t0, tT, wa);
+            load_window32(vP, p0, tP, wb);
+            // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any
+            // high bit sends the row to the code-point kernel; the varying low bits decide how many bit-planes
+            // the match masks need
+            uint32_t any;
+            const uint32_t vary = window_vary(wa, wb, any);
+            if (fast && (any & 0x80u)) {
+                fast = false;
+                atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
             }
             if (__ballot(fast) == 0ull) continue;
-            if (SYMMETRIC && la8 > lb8) { // walk the shorter string: swap roles
-#pragma unroll
-                for (int d = 0; d < 8; ++d) { const uint32_t t = wa[d]; wa[d] = wb[d]; wb[d] = t; }
-                const uint32_t t = la8; la8 = lb8; lb8 = t;
-            }
             const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
             const uint32_t tmax = wave_max_round4(la);
             const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;

@@ -163,11 +163,15 @@ STRSIM_HD int planes_needed(uint32_t vary) { return (vary & 0x40u) ? 7 : ((vary 
 // Varying bits of the 64 bytes of two windows, folded to the low 8 bits; `any` gets the OR of all bytes.
 STRSIM_HD uint32_t window_vary(const uint32_t (&wa)[8], const uint32_t (&wb)[8], uint32_t &any)
 {
-    uint32_t o = wa[0], n = wa[0];
-#pragma unroll
-    for (int d = 1; d < 8; ++d) { o |= wa[d]; n &= wa[d]; }
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { o |= wb[d]; n &= wb[d]; }
+    // three-input OR (0xFE) / AND (0x80): 8 + 8 ops for the sixteen dwords
+    uint32_t o = bitop3<0xFE>(wa[0], wa[1], wa[2]), n = bitop3<0x80>(wa[0], wa[1], wa[2]);
+    o = bitop3<0xFE>(o, wa[3], wa[4]); n = bitop3<0x80>(n, wa[3], wa[4]);
+    o = bitop3<0xFE>(o, wa[5], wa[6]); n = bitop3<0x80>(n, wa[5], wa[6]);
+    o = bitop3<0xFE>(o, wa[7], wb[0]); n = bitop3<0x80>(n, wa[7], wb[0]);
+    o = bitop3<0xFE>(o, wb[1], wb[2]); n = bitop3<0x80>(n, wb[1], wb[2]);
+    o = bitop3<0xFE>(o, wb[3], wb[4]); n = bitop3<0x80>(n, wb[3], wb[4]);
+    o = bitop3<0xFE>(o, wb[5], wb[6]); n = bitop3<0x80>(n, wb[5], wb[6]);
+    o |= wb[7]; n &= wb[7];
     // fold the four byte lanes: OR of ORs, AND of ANDs
     uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
     uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
