@@ -193,7 +193,7 @@ def main():
                          "kernel_ms": lane_ms, "wave_kernel_ms": wave_ms,
                          "achieved_read_plus_write": (read_bytes + write_bytes) / (lane_ms * 1e-3) / 1e9 if lane_ms > 0 else 0.0},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
             try:
                 cb, (n_s, exp) = cpu_baseline(measures[0], cfg, rows)
                 res["cpu_baseline"] = cb

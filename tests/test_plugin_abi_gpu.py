@@ -118,3 +118,28 @@ def test_threaded_packing_and_multi_slice_pipeline(H):
         ok = ~mask
         assert np.isnan(g[mask]).all()
         assert (g[ok].view(np.uint64) == exp[ok].view(np.uint64)).all()
+
+
+def test_concurrent_calls_from_several_threads(H):
+    """Polars may call the plugin from several of its threads at once (is_elementwise=True): thread-local contexts
+    and error slots must keep the calls independent."""
+    import threading
+    A, B = gen.pairs(55, 60000, gen.ASCII_LOWER, 0, 40)
+    exp = {m: expect(m, A, B) for m in O.MEASURES}
+    errs = []
+
+    def work(m, reps):
+        try:
+            for _ in range(reps):
+                check(H.call_plugin(m, A, B), exp[m])
+            with pytest.raises(H.PluginError, match="same length"):
+                H.call_plugin(m, A[:3], B[:5])
+        except BaseException as e:  # noqa: BLE001
+            errs.append((m, repr(e)))
+
+    th = [threading.Thread(target=work, args=(m, 3)) for m in O.MEASURES for _ in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
