@@ -328,13 +328,15 @@ struct ThreadCtx {
     strsim_ctx_t *ctx = nullptr;
     int device = 0;
     Slot slot[2];
-    Buf lit_off, lit_val; // device copy of a literal side
+    Buf lit_off, lit_val;     // device copy of a literal side
+    Buf lit_h_off, lit_h_val; // its pinned host staging
     ~ThreadCtx()
     {
         if (ctx) {
             (void)hipSetDevice(device);
             for (auto &s : slot) s.release();
             lit_off.release(); lit_val.release();
+            lit_h_off.release(); lit_h_val.release();
             strsim_ctx_destroy(ctx);
         }
     }
@@ -417,16 +419,13 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         const uint8_t *lit_val_d = nullptr;
         for (int s = 0; s < 2; ++s) {
             if (!lit[s]) continue;
-            Buf ho, hv;
-            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1);
-            if (bytes > SLICE_BYTES) { ho.release(); hv.release(); fail("a single string exceeds the 4 GiB limit"); }
+            Buf &ho = g_ctx.lit_h_off, &hv = g_ctx.lit_h_val; // persistent pinned staging: the call is synchronous,
+            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
+            if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
             g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
             g_ctx.lit_val.reserve(bytes + 64);
-            hipError_t e1 = hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-            hipError_t e2 = bytes ? hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream) : hipSuccess;
-            hipError_t e3 = hipStreamSynchronize(stream);
-            ho.release(); hv.release();
-            HIP_OR_FAIL(e1); HIP_OR_FAIL(e2); HIP_OR_FAIL(e3);
+            HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            if (bytes) HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream));
             lit_off_d = static_cast<const uint32_t *>(g_ctx.lit_off.p);
             lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
         }
