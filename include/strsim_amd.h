@@ -99,6 +99,16 @@ STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
                         double *out, uint64_t out_rows);
 
+/*
+ * All five measures of the same two column shards in one call (BASELINE config 4): the rows that fit the
+ * lane-per-pair path are read once and produce five outputs from one set of bit-planes; `outs` is indexed by
+ * strsim_measure_t, five device buffers of out_rows doubles.  Same asynchronous contract as above.
+ */
+STRSIM_API int strsim_pairs_device_all(strsim_ctx_t *ctx,
+                            const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
+                            const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
+                            double *const outs[5], uint64_t out_rows);
+
 /* Wait for everything enqueued through this context and surface any deferred error. */
 STRSIM_API int strsim_ctx_synchronize(strsim_ctx_t *ctx);
 

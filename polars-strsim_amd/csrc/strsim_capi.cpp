@@ -66,7 +66,8 @@ struct strsim_ctx {
     bool slot_pending[RING] = {};
     bool slot_timed[RING] = {};
     LaunchArgs slot_args[RING] = {}; // what each pending call was launched with (for the long-string pass)
-    int slot_measure[RING] = {};
+    int slot_measure[RING] = {};     // STRSIM_NUM_MEASURES = the fused all-measures call
+    double *slot_outs[RING][5] = {};
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
     int head = 0;
@@ -96,8 +97,16 @@ static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
     if (rc) return rc;
     LaunchArgs a = c->slot_args[slot];
     a.ev_lane0 = a.ev_lane1 = a.ev_wave1 = nullptr;
-    hipError_t e = launch_huge(c->slot_measure[slot], a, c->huge_ws, cap, (int)waves);
-    if (e != hipSuccess) return hip_fail(e, "long-string kernel launch");
+    if (c->slot_measure[slot] == STRSIM_NUM_MEASURES) {
+        for (int m = 0; m < STRSIM_NUM_MEASURES; ++m) {
+            a.out = c->slot_outs[slot][m];
+            hipError_t e = launch_huge(m, a, c->huge_ws, cap, (int)waves);
+            if (e != hipSuccess) return hip_fail(e, "long-string kernel launch");
+        }
+    } else {
+        hipError_t e = launch_huge(c->slot_measure[slot], a, c->huge_ws, cap, (int)waves);
+        if (e != hipSuccess) return hip_fail(e, "long-string kernel launch");
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return STRSIM_OK;
 }
@@ -222,11 +231,13 @@ void strsim_split_offsets(uint64_t len, uint64_t n, uint64_t *out)
     }
 }
 
-int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
-                        const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *out, uint64_t out_rows)
+static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                             const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *const *outs,
+                             uint64_t out_rows)
 {
+    const bool all = measure == STRSIM_NUM_MEASURES;
     if (!c) { set_error("strsim_pairs_device: ctx is NULL"); return STRSIM_ERR_ARG; }
-    if (measure < 0 || measure >= STRSIM_NUM_MEASURES) {
+    if (measure < 0 || measure > STRSIM_NUM_MEASURES) {
         set_error("strsim_pairs_device: unknown measure %d", measure);
         return STRSIM_ERR_ARG;
     }
@@ -242,7 +253,9 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
         return STRSIM_ERR_ARG;
     }
     if (n == 0) return STRSIM_OK;
-    if (!a_off || !b_off || !out) { set_error("strsim_pairs_device: NULL buffer"); return STRSIM_ERR_ARG; }
+    if (!a_off || !b_off || !outs) { set_error("strsim_pairs_device: NULL buffer"); return STRSIM_ERR_ARG; }
+    for (int q = 0; q < (all ? STRSIM_NUM_MEASURES : 1); ++q)
+        if (!outs[q]) { set_error("strsim_pairs_device: NULL output buffer"); return STRSIM_ERR_ARG; }
     int rc = ctx_set_device(c);
     if (rc) return rc;
     // the ring slot about to be reused must have been retired
@@ -252,14 +265,14 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
         if (rc) return rc;
     }
     const uint64_t nchunks = (n + 63) >> 6;
-    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, nchunks * sizeof(unsigned long long));
+    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long));
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->status + slot, 0, sizeof(DevStatus), c->stream));
 
     LaunchArgs la;
     la.offA = a_off; la.valA = a_val; la.rowsA = a_rows;
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
-    la.out = out; la.n = n;
+    la.out = outs[0]; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
@@ -270,15 +283,31 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
             if (!c->ev[slot][i]) HIP_TRY(hipEventCreate(&c->ev[slot][i]));
         la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
     }
-    hipError_t e = launch_pairs(measure, la);
+    hipError_t e = all ? launch_pairs_all(la, outs, c->slowmask + nchunks) : launch_pairs(measure, la);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     c->slot_timed[slot] = c->timing;
     c->slot_args[slot] = la;
     c->slot_measure[slot] = measure;
+    for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = all ? outs[q] : nullptr;
     HIP_TRY(hipMemcpyAsync(c->status_host + slot, c->status + slot, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
     c->slot_pending[slot] = true;
     c->head = (slot + 1) % strsim_ctx::RING;
     return STRSIM_OK;
+}
+
+int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                        const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *out, uint64_t out_rows)
+{
+    if (measure == STRSIM_NUM_MEASURES) { set_error("strsim_pairs_device: unknown measure %d", measure); return STRSIM_ERR_ARG; }
+    double *outs[1] = {out};
+    return pairs_device_impl(c, measure, a_off, a_val, a_rows, b_off, b_val, b_rows, out ? outs : nullptr, out_rows);
+}
+
+int strsim_pairs_device_all(strsim_ctx_t *c, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                            const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *const outs[5],
+                            uint64_t out_rows)
+{
+    return pairs_device_impl(c, STRSIM_NUM_MEASURES, a_off, a_val, a_rows, b_off, b_val, b_rows, outs, out_rows);
 }
 
 int strsim_ctx_synchronize(strsim_ctx_t *c)

@@ -27,6 +27,9 @@ struct LaunchArgs {
 
 hipError_t launch_pairs(int measure, const LaunchArgs &a);
 
+// All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
+hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);
+
 // Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with 3 * (cap + 64) words of `ws`.
 hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid);
 

@@ -94,29 +94,37 @@ __device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
     return 4u * (g + 1u);
 }
 
+constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
+
+struct OutPtrs {
+    double *p[5]; // indexed by Measure; single-measure kernels use p[0]
+};
+
 template <int MEASURE>
 __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__restrict__ offA,
                                                            const uint8_t *__restrict__ valA, uint64_t rowsA,
                                                            const uint32_t *__restrict__ offB,
                                                            const uint8_t *__restrict__ valB, uint64_t rowsB,
-                                                           double *__restrict__ out, uint64_t n,
+                                                           OutPtrs outs, uint64_t n,
                                                            unsigned long long *__restrict__ slowmask)
 {
+    constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
     __shared__ uint32_t s_cnt[2][8];                    // bucket counters (double-buffered by block parity)
     __shared__ unsigned long long s_late[2][LANE_ROUNDS]; // rows found non-ASCII after their bytes were loaded
     __shared__ uint16_t s_perm[LANE_ROWS];
     __shared__ uint32_t s_a0[LANE_ROWS];
     __shared__ uint32_t s_b0[LANE_ROWS];
     __shared__ uint32_t s_len[LANE_ROWS];               // la | lb << 16, or ~0 for rows this kernel skips
-    __shared__ double s_out[LANE_ROWS];
-    __shared__ double s_levtab[MEASURE == LEVENSHTEIN ? 33 * 33 : 1];
+    __shared__ double s_out[NOUT][LANE_ROWS];
+    constexpr bool HAS_LEV = MEASURE == LEVENSHTEIN || MEASURE == ALL_MEASURES;
+    __shared__ double s_levtab[HAS_LEV ? 33 * 33 : 1];
 
     // Levenshtein distance and the multiset intersection do not depend on the argument order
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wv = tid >> 6;
-    if (MEASURE == LEVENSHTEIN) {
+    if (HAS_LEV) {
         // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: same IEEE division as the
         // epilogue, done once per workgroup instead of once per pair
         for (uint32_t i = tid; i < 33u * 33u; i += LANE_BLOCK) {
@@ -207,11 +215,23 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
             const uint32_t tmax = wave_max_round4(la);
             const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
             const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
-            double res;
-            if (need7) res = lane_pair_result<MEASURE, 7>(wa, la, wb, lb, tmax, s_levtab);
-            else if (need6) res = lane_pair_result<MEASURE, 6>(wa, la, wb, lb, tmax, s_levtab);
-            else res = lane_pair_result<MEASURE, 5>(wa, la, wb, lb, tmax, s_levtab);
-            if (fast) s_out[idx] = res;
+            if (MEASURE == ALL_MEASURES) {
+                double res[5];
+                if (need7) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res);
+                else if (need6) lane_all_results<6>(wa, la, wb, lb, tmax, s_levtab, res);
+                else lane_all_results<5>(wa, la, wb, lb, tmax, s_levtab, res);
+                if (fast) {
+#pragma unroll
+                    for (int q = 0; q < NOUT; ++q) s_out[q][idx] = res[q];
+                }
+            } else {
+                constexpr int M1 = MEASURE == ALL_MEASURES ? 0 : MEASURE;
+                double res;
+                if (need7) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab);
+                else if (need6) res = lane_pair_result<M1, 6>(wa, la, wb, lb, tmax, s_levtab);
+                else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab);
+                if (fast) s_out[0][idx] = res;
+            }
         }
         __syncthreads();
         // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
@@ -220,7 +240,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
             const uint32_t i = q * LANE_BLOCK + tid;
             const uint64_t row = row0 + i;
             const unsigned long long sk = skip[q] | s_late[par][i >> 6];
-            if (!((sk >> lane) & 1ull)) out[row] = s_out[i];
+            if (!((sk >> lane) & 1ull)) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) outs.p[o][row] = s_out[o][i];
+            }
             if (lane == 0u && row < n)
                 slowmask[row >> 6] = sk & (n - row >= 64u ? ~0ull : ((1ull << (n - row)) - 1ull));
         }
@@ -898,8 +921,10 @@ static void launch_pair(const LaunchArgs &a)
     const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
     const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
+    OutPtrs op{};
+    op.p[0] = a.out;
     hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, a.out, a.n, a.slowmask);
+                       a.valB, a.rowsB, op, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
         const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
@@ -929,6 +954,50 @@ hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t 
     case SORENSEN_DICE: launch_huge_t<SORENSEN_DICE>(a, ws, cap, grid); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+template <int M>
+static void launch_slow_kernels(const LaunchArgs &a, double *out)
+{
+    const uint64_t nchunks = (a.n + 63u) >> 6;
+    const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
+    const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
+    const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
+    hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask);
+    hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask, a.status);
+}
+
+// All five measures of one frame: one fused lane kernel (five outputs), then the slow-row kernels per measure,
+// each starting from the same mask (k_lane_wide clears what it finishes, so the mask is restored in between).
+hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup)
+{
+    if (a.n == 0) return hipSuccess;
+    const uint64_t nchunks = (a.n + 63u) >> 6;
+    const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
+    const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
+    OutPtrs op{};
+    for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
+    if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
+    hipLaunchKernelGGL((k_lane_pairs<ALL_MEASURES>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
+                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask);
+    if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
+    hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
+    if (e != hipSuccess) return e;
+    launch_slow_kernels<LEVENSHTEIN>(a, outs[LEVENSHTEIN]);
+    for (int m = 1; m < 5; ++m) {
+        e = hipMemcpyAsync(a.slowmask, mask_backup, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
+        if (e != hipSuccess) return e;
+        switch (m) {
+        case JARO: launch_slow_kernels<JARO>(a, outs[m]); break;
+        case JARO_WINKLER: launch_slow_kernels<JARO_WINKLER>(a, outs[m]); break;
+        case JACCARD: launch_slow_kernels<JACCARD>(a, outs[m]); break;
+        default: launch_slow_kernels<SORENSEN_DICE>(a, outs[m]); break;
+        }
+    }
+    if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
     return hipGetLastError();
 }
 

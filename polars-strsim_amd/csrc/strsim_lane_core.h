@@ -388,4 +388,37 @@ STRSIM_HD double lane_pair_result(const uint32_t (&wa)[8], uint32_t la, const ui
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// All five measures of one pair from one set of bit-planes (BASELINE config 4): the planes of b are built once,
+// Jaro's matching serves both Jaro and Jaro-Winkler, the multiset intersection serves Jaccard and Dice.
+// r[] is indexed by Measure.  No role swap here: Jaro walks a, so every measure does.
+// ---------------------------------------------------------------------------------------------
+template <int NP>
+STRSIM_HD void lane_all_results(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
+                                uint32_t tmax, const double *levtab, double (&r)[5])
+{
+    uint32_t P[NP];
+    build_planes<NP>(wb, P);
+    const bool live = la != 0u && lb != 0u;
+    const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
+    uint32_t m, t;
+    jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
+    const double j = epilogue_jaro(m, t, la1, lb1);
+    r[JARO] = j;
+    r[JARO_WINKLER] = epilogue_jaro_winkler(j, common_prefix4(wa[0], la1, wb[0], lb1));
+    const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
+    r[JACCARD] = epilogue_jaccard(isect, la1, lb1);
+    r[SORENSEN_DICE] = epilogue_sorensen_dice(isect, la1, lb1);
+    const uint32_t s = 32u - lb1;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) P[k] <<= s;
+    const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
+    r[LEVENSHTEIN] = levtab ? levtab[dist * 33u + (la1 > lb1 ? la1 : lb1)] : epilogue_levenshtein(dist, la1, lb1);
+    if (!live) {
+        const double v = (la == 0u && lb == 0u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = v;
+    }
+}
+
 } // namespace strsim

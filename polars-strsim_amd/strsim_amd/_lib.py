@@ -57,6 +57,8 @@ def lib():
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [vp, i32, vp, vp, u64, vp, vp, u64, vp, u64]
+    L.strsim_pairs_device_all.restype = i32
+    L.strsim_pairs_device_all.argtypes = [vp, vp, vp, u64, vp, vp, u64, C.POINTER(vp), u64]
     L.strsim_ctx_synchronize.restype = i32
     L.strsim_ctx_synchronize.argtypes = [vp]
     L.strsim_split_offsets.restype = None

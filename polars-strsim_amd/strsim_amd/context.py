@@ -84,6 +84,18 @@ class Context:
                                         out.data_ptr(), out.numel()))
         return out
 
+    def pairs_device_all(self, a_offsets, a_values, b_offsets, b_values, outs=None):
+        """All five measures in one fused call -> list of five f64 tensors indexed like MEASURES."""
+        import torch
+        ra, rb = a_offsets.numel() - 1, b_offsets.numel() - 1
+        n = rb if ra == 1 else ra
+        if outs is None:
+            outs = [torch.empty(n, dtype=torch.float64, device=a_offsets.device) for _ in range(5)]
+        arr = (C.c_void_p * 5)(*[o.data_ptr() for o in outs])
+        check(lib().strsim_pairs_device_all(self._h, a_offsets.data_ptr(), a_values.data_ptr(), ra,
+                                            b_offsets.data_ptr(), b_values.data_ptr(), rb, arr, n))
+        return outs
+
     # ---- host-resident (numpy) ---------------------------------------------------------------------
     def pairs_host(self, measure, a_offsets, a_values, b_offsets, b_values):
         """Synchronous: numpy uint32 offsets + uint8 values in, numpy f64 out."""

@@ -186,3 +186,26 @@ def test_anchor_bits(S):
     assert bits(S.jaro_winkler(a, b)[0]) == 0x3FEF333333333333
     assert bits(S.jaccard(a, b)[0]) == 0x3FEC000000000000
     assert bits(S.sorensen_dice(a, b)[0]) == 0x3FEDDDDDDDDDDDDE
+
+
+def test_fused_all_measures_equals_single_measure_kernels(S):
+    """strsim_pairs_device_all: five outputs from one pass == the five single-measure calls, bit for bit
+    (mixed frame: lane path, wide path, wave path, a > 1024-byte row)."""
+    import torch
+    A, B = gen.pairs(71, 30000, gen.ASCII_LOWER, 0, 32)
+    A2, B2 = gen.pairs(72, 3000, gen.ASCII_LOWER, 20, 128)
+    A3, B3 = gen.pairs(73, 500, gen.MIXED, 0, 60)
+    A, B = A + A2 + A3 + ["x" * 1500], B + B2 + B3 + ["x" * 700 + "y" * 700]
+    ao, av = S.pack_strings(A)
+    bo, bv = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    cols = (t(ao, np.int32), t(np.concatenate([av, pad]), np.uint8), t(bo, np.int32), t(np.concatenate([bv, pad]), np.uint8))
+    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+        outs = ctx.pairs_device_all(*cols)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        for m, o in zip(S.MEASURES, outs):
+            exp = O.batch_strings(m, A, B, 8)
+            assert_bit_exact(o.cpu().numpy(), exp, A, B, "fused " + m)
