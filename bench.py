@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the control flow)")
     p.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     p.add_argument("--cpu-sample-rows", type=int, default=0)
+    p.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive plugin-ABI measurement (N=1 extra field)")
     return p.parse_args()
 
 
@@ -65,6 +66,28 @@ def cpu_baseline(measure, cfg, rows_total):
     return {"value": n / dt / 1e6, "unit": "M string-pairs/s", "cores": cores, "kind": "port",
             "sample": f"first {n} rows of the same synthetic frame, {dt:.1f} s wall, oracle/strsim_oracle.c on {cores} threads "
                       f"(split_offsets partition)"}, (n, out)
+
+
+def plugin_e2e(measure, cfg, rows):
+    """PCIe-inclusive rate through _polars_plugin_<measure> (host Arrow string views in, host f64 out) on a prefix."""
+    import numpy as np
+    import pyarrow as pa
+    from bench_support import workload as W
+    from strsim_amd import arrow_host as H
+    _, _, law, lo, hi, seed = cfg
+    n = min(rows, 8_000_000 if hi <= 128 else 200_000)
+    oa, va, ob, vb = W.host_columns(seed, law, lo, hi, 0, n)
+    mk = lambda o, v: pa.StringArray.from_buffers(n, pa.py_buffer(o.astype(np.int32)), pa.py_buffer(v)).cast(pa.string_view())
+    a, b = mk(oa, va), mk(ob, vb)
+    H.call_plugin(measure, a[:1000], b[:1000])
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        H.call_plugin(measure, a, b)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": n / best / 1e6, "unit": "M string-pairs/s", "rows": n, "layout": "Utf8View",
+            "note": "host Arrow views -> host f64 through the plugin C ABI (pack + H2D + kernels + D2H); never `value`"}
 
 
 def main():
@@ -209,6 +232,16 @@ def main():
                          "kernel_ms": lane_ms, "wave_kernel_ms": wave_ms,
                          "achieved_read_plus_write": (read_bytes + write_bytes) / (lane_ms * 1e-3) / 1e9 if lane_ms > 0 else 0.0},
         }
+        if a.config == "cfg5" or hi > 128:
+            la_ = (offA[1:] - offA[:-1]).to(torch.float64)
+            lb_ = (offB[1:] - offB[:-1]).to(torch.float64)
+            cells = float((la_ * lb_).sum().item())
+            res["gcups"] = cells * len(measures) * a.steps / dt / 1e9  # DP cells per second (compute-bound workloads)
+        if not a.no_e2e and world == 1 and len(measures) == 1:
+            try:
+                res["end_to_end_plugin_abi"] = plugin_e2e(measures[0], cfg, rows)
+            except Exception as e:
+                res["end_to_end_plugin_abi"] = {"value": None, "note": "failed: %r" % (e,)}
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
             try:
                 cb, (n_s, exp) = cpu_baseline(measures[0], cfg, rows)
