@@ -576,6 +576,7 @@ struct BlockJob {
     uint32_t n;          // length of the shorter string (staged in LDS)
 };
 
+template <int NP>
 __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const BlockJob &j1, const uint8_t *txt0,
                                                  const uint8_t *txt1, uint32_t &dist0, uint32_t &dist1)
 {
@@ -592,8 +593,8 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
 #pragma unroll
     for (int d = 0; d < 8; ++d) w[d] = 0u;
     if (mine) load_window_any<8>(valP, (int64_t)p0 + (int64_t)m - 32 * (int64_t)(B - blk), totalP, w);
-    uint32_t P[7];
-    build_planes<7>(w, P);
+    uint32_t P[NP];
+    build_planes<NP>(w, P);
     const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
     const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
@@ -608,7 +609,7 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
         const uint32_t j = t - blk;
         if (mine && j < n) {
             const uint32_t c = txt[j];
-            uint32_t Eq = eq_mask<7>(P, valid, c, 0);
+            uint32_t Eq = eq_mask<NP>(P, valid, c, 0);
             const uint32_t hinP = hin & 1u, hinN = hin >> 1;
             const uint32_t Xv = Eq | Mv;
             Eq |= hinN;
@@ -629,15 +630,22 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
 }
 
 // Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
-__device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ p, uint32_t len, uint8_t *dst)
+// or6/and6 accumulate, wave-uniformly, whether bits 5 and 6 are set in any / in every byte (plane-count choice).
+__device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ p, uint32_t len, uint8_t *dst, uint32_t &or6,
+                                                 uint32_t &and6)
 {
     const uint32_t lane = lane_id();
     bool ascii = true;
     for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
         const uint32_t i = c0 + lane;
-        const uint32_t b = i < len ? p[i] : 0u;
+        const bool in = i < len;
+        const uint32_t b = in ? p[i] : 0u;
         if (__ballot(b >= 0x80u) != 0ull) ascii = false;
-        if (dst && i < len) dst[i] = (uint8_t)b;
+        if (__ballot(in && (b & 0x20u)) != 0ull) or6 |= 0x20u;
+        if (__ballot(in && (b & 0x40u)) != 0ull) or6 |= 0x40u;
+        if (__ballot(in && !(b & 0x20u)) != 0ull) and6 &= ~0x20u;
+        if (__ballot(in && !(b & 0x40u)) != 0ull) and6 &= ~0x40u;
+        if (dst && in) dst[i] = (uint8_t)b;
     }
     return ascii;
 }
@@ -787,6 +795,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     __shared__ uint32_t sB[WAVE_CAP];
     __shared__ uint32_t aux[WAVE_CAP + 64];
     __shared__ uint8_t s_txt8[MEASURE == LEVENSHTEIN ? 2 : 1][MEASURE == LEVENSHTEIN ? WAVE_CAP : 4];
+    __shared__ uint8_t s_order[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
@@ -797,12 +806,18 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint64_t job_row[2] = {0, 0};
     uint32_t job_la[2] = {0, 0}, job_lb[2] = {0, 0};
     uint32_t njobs = 0;
+    uint32_t job_or6 = 0u, job_and6 = 0x60u; // bits 5/6 over the bytes of the pending jobs
     auto flush_jobs = [&]() {
         if (MEASURE != LEVENSHTEIN || njobs == 0u) return;
         if (njobs == 1u) job[1] = BlockJob{nullptr, 0, 0, 0, 0};
         __syncthreads();
         uint32_t d0, d1;
-        wave_lev_blocks2(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+        // five planes when bits 5 and 6 are constant over every byte of both jobs (a-z), else all seven
+        if ((job_or6 ^ job_and6) & 0x60u)
+            wave_lev_blocks2<7>(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+        else
+            wave_lev_blocks2<5>(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+        job_or6 = 0u; job_and6 = 0x60u;
         if (lane == 0u) {
             out[job_row[0]] = epilogue_levenshtein(d0, job_la[0], job_lb[0]);
             if (njobs == 2u) out[job_row[1]] = epilogue_levenshtein(d1, job_la[1], job_lb[1]);
@@ -826,9 +841,37 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
             unsigned long long mask =
                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
-            while (mask != 0ull) {
-                const uint32_t bitpos = (uint32_t)__builtin_ctzll(mask);
-                mask &= mask - 1ull;
+            // Levenshtein runs two rows at a time for max(steps) of the two: visit the chunk's rows in descending
+            // order of their step count (shorter length + blocks of the longer - 1) so that partners are alike
+            uint32_t nvisit = (uint32_t)__popcll(mask);
+            if (MEASURE == LEVENSHTEIN && nvisit > 2u) {
+                uint32_t key = 0u;
+                const bool mine = (mask >> lane) & 1ull;
+                if (mine) {
+                    const uint64_t rw = chunk * 64u + lane;
+                    const uint64_t ra = bcastA ? 0 : rw, rb = bcastB ? 0 : rw;
+                    const uint32_t x = offA[ra + 1] - offA[ra], y = offB[rb + 1] - offB[rb];
+                    const uint32_t mx = x > y ? x : y, mn = x < y ? x : y;
+                    key = (mn != 0u && mx <= (uint32_t)WAVE_CAP) ? mn + ((mx + 31u) >> 5) : 0u;
+                }
+                uint32_t rank = 0u;
+                for (unsigned long long mm = mask; mm != 0ull; mm &= mm - 1ull) {
+                    const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
+                    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)jl);
+                    rank += (kj > key || (kj == key && jl < lane)) ? 1u : 0u;
+                }
+                __syncthreads();
+                if (mine) s_order[rank] = (uint8_t)lane;
+                __syncthreads();
+            }
+            for (uint32_t vi = 0; vi < nvisit; ++vi) {
+                uint32_t bitpos;
+                if (MEASURE == LEVENSHTEIN && nvisit > 2u) {
+                    bitpos = uniform((uint32_t)s_order[vi]);
+                } else {
+                    bitpos = (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                }
                 const uint64_t row = chunk * 64u + bitpos;
                 const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
                 const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
@@ -846,9 +889,11 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const bool a_long = la8 >= lb8;
                     const uint8_t *ps = a_long ? valB + b0 : valA + a0;
                     const uint32_t ns = a_long ? lb8 : la8;
-                    const bool asc_l = wave_ascii_stage(a_long ? valA + a0 : valB + b0, a_long ? la8 : lb8, nullptr);
-                    const bool asc_s = wave_ascii_stage(ps, ns, s_txt8[njobs & 1u]);
+                    uint32_t o6 = job_or6, n6 = job_and6;
+                    const bool asc_l = wave_ascii_stage(a_long ? valA + a0 : valB + b0, a_long ? la8 : lb8, nullptr, o6, n6);
+                    const bool asc_s = wave_ascii_stage(ps, ns, s_txt8[njobs & 1u], o6, n6);
                     if (asc_l && asc_s) {
+                        job_or6 = o6; job_and6 = n6;
                         job[njobs] = a_long ? BlockJob{valA, a0, la8, totalA, ns} : BlockJob{valB, b0, lb8, totalB, ns};
                         job_row[njobs] = row;
                         job_la[njobs] = la8;
