@@ -82,6 +82,16 @@ def test_lane_path_random(S, ctx, measure, alphabet, lo, hi):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+def test_embedded_nul_and_control_bytes(S, ctx, measure):
+    """A Rust &str may hold any scalar value, U+0000 included."""
+    A, B = gen.pairs(91, 8000, "ab\x00\x01\x7f ", 0, 32)
+    A2, B2 = gen.pairs(92, 1000, "ab\x00\x7fé", 0, 80)
+    A, B = A + A2, B + B2
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_wave_path_unicode_and_long(S, ctx, measure):
     A, B = gen.pairs(11, 3000, gen.MIXED, 0, 40)
     A2, B2 = gen.pairs(12, 600, gen.ASCII_LOWER, 20, 300)
