@@ -139,6 +139,30 @@ STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms,
  * (valid after strsim_ctx_synchronize()). */
 STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
 
+/*
+ * Lossless 16-bit transport codec for result columns (csrc/strsim_codec.hip).  A similarity of two strings of at
+ * most `max_chars` characters takes few distinct values (max_chars = 32: 325 / 22 856 / 57 359 / 631 / 631 for the
+ * five measures); the codec ships the 16-bit rank of each value instead of 8 bytes -- 4x less traffic on the
+ * point-to-point xGMI link of a gather -- and decodes bit-exactly.  Values outside the table (rows with longer
+ * strings) are coded 0xFFFF and reported as (row, value) exceptions.  All buffers are device memory of the
+ * context's GPU; calls are asynchronous on the context's stream.
+ */
+typedef struct strsim_codec strsim_codec_t;
+/* Fails with STRSIM_ERR_ARG when the value set does not fit 16 bits (e.g. Jaro with max_chars = 128). */
+STRSIM_API int strsim_codec_create(strsim_ctx_t *ctx, int measure, uint32_t max_chars, strsim_codec_t **out);
+STRSIM_API void strsim_codec_destroy(strsim_codec_t *codec);
+STRSIM_API uint32_t strsim_codec_entries(const strsim_codec_t *codec);
+/* vals[n] -> codes[n]; *exc_count (device) = number of exceptions, the first exc_cap of them in exc_rows/exc_vals. */
+STRSIM_API int strsim_codec_encode(strsim_ctx_t *ctx, const strsim_codec_t *codec, const double *vals, uint64_t n,
+                                   uint16_t *codes, uint32_t *exc_count, uint32_t *exc_rows, double *exc_vals,
+                                   uint32_t exc_cap);
+/* codes[n] -> out[n]; rows coded 0xFFFF are left untouched. */
+STRSIM_API int strsim_codec_decode(strsim_ctx_t *ctx, const strsim_codec_t *codec, const uint16_t *codes, uint64_t n,
+                                   double *out);
+/* out[row_base + exc_rows[i]] = exc_vals[i] for i < count. */
+STRSIM_API int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_rows,
+                                  const double *exc_vals, uint32_t count);
+
 #define STRSIM_LANE_PATH_MAX_BYTES 32u   /* lane-per-pair kernels: both strings <= 32 bytes, ASCII */
 #define STRSIM_WAVE_PATH_MAX_BYTES 1024u /* wave-per-pair kernels: both strings <= 1024 bytes, any UTF-8 */
 

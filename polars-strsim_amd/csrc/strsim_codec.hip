@@ -1,0 +1,239 @@
+// strsim_codec.hip -- lossless 16-bit transport codec for result columns.
+//
+// Why: the one collective of the path is the gather of the f64 result shards to rank 0 over xGMI, and xGMI is
+// point-to-point: every peer owns ONE link into the root (~50-70 GB/s per direction).  A 100 M-row shard is
+// 800 MB of f64 -- 12-16 ms on a link, against ~2.3 ms of kernel time.  But a similarity of two strings of at
+// most L characters can only take a small set of values (L = 32: 325 for Levenshtein, 631 for Jaccard/Dice,
+// 22 856 for Jaro, 57 359 for Jaro-Winkler), because it is a fixed IEEE expression of a few small integers.
+// The codec enumerates that set with the library's own epilogues (same operations, same order => same bits),
+// sorts it, and ships the 16-bit rank of each value instead of the value: 4x fewer bytes per link, bit-exact.
+// A value that is not in the table (a row with a longer string) gets code 0xFFFF and travels as an explicit
+// (row, value) exception.
+//
+//   encode: f64[n] -> u16[n] (+ exceptions)    hash lookup keyed by the f64 bit pattern (open addressing, L2-resident)
+//   decode: u16[n] -> f64[n]                   table[code]; 0xFFFF rows are left for the exception patch
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "strsim_amd.h"
+#include "strsim_internal.h"
+#include "strsim_lane_core.h"
+
+using namespace strsim;
+
+struct strsim_codec {
+    int measure = 0;
+    uint32_t max_chars = 0;
+    uint32_t entries = 0;
+    uint32_t hash_mask = 0;
+    double *d_table = nullptr;            // sorted distinct values, entries long
+    unsigned long long *d_keys = nullptr; // hash table: value bit patterns (EMPTY = all ones)
+    uint16_t *d_vals = nullptr;           // hash table: code of the key in the same slot
+};
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = ~0ull; // a NaN pattern: never a similarity
+
+__host__ __device__ inline uint32_t hash_bits(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xFF51AFD7ED558CCDull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+inline unsigned long long bits_of(double v)
+{
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    return b;
+}
+
+// every value `measure` can take on two strings of 0..L characters
+void enumerate_values(int measure, uint32_t L, std::vector<double> &out)
+{
+    out.push_back(1.0); // both empty, or equal
+    out.push_back(0.0); // one side empty
+    switch (measure) {
+    case LEVENSHTEIN:
+        for (uint32_t den = 1; den <= L; ++den)
+            for (uint32_t d = 0; d <= den; ++d) out.push_back(epilogue_levenshtein(d, den, den));
+        break;
+    case JACCARD:
+    case SORENSEN_DICE:
+        for (uint32_t la = 1; la <= L; ++la)
+            for (uint32_t lb = la; lb <= L; ++lb)
+                for (uint32_t i = 0; i <= la; ++i)
+                    out.push_back(measure == JACCARD ? epilogue_jaccard(i, la, lb) : epilogue_sorensen_dice(i, la, lb));
+        break;
+    case JARO:
+    case JARO_WINKLER:
+        for (uint32_t la = 1; la <= L; ++la)
+            for (uint32_t lb = 1; lb <= L; ++lb) {
+                const uint32_t mn = la < lb ? la : lb;
+                for (uint32_t m = 1; m <= mn; ++m)
+                    for (uint32_t t = 0; t <= m; t += 2) { // only t/2 matters
+                        const double j = epilogue_jaro(m, t, la, lb);
+                        if (measure == JARO) { out.push_back(j); continue; }
+                        const uint32_t pmax = mn < 4u ? mn : 4u;
+                        for (uint32_t p = 0; p <= pmax; ++p) out.push_back(epilogue_jaro_winkler(j, p));
+                    }
+            }
+        break;
+    default: break;
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+__global__ void k_encode(const double *__restrict__ vals, uint64_t n, uint16_t *__restrict__ codes,
+                         const unsigned long long *__restrict__ keys, const uint16_t *__restrict__ kvals, uint32_t mask,
+                         uint32_t *__restrict__ exc_count, uint32_t *__restrict__ exc_rows, double *__restrict__ exc_vals,
+                         uint32_t exc_cap)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double v = vals[i];
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        uint32_t h = hash_bits(b) & mask;
+        uint16_t code = 0xFFFFu;
+        for (;;) {
+            const unsigned long long k = keys[h];
+            if (k == b) { code = kvals[h]; break; }
+            if (k == EMPTY_KEY) break;
+            h = (h + 1u) & mask;
+        }
+        codes[i] = code;
+        if (code == 0xFFFFu) {
+            const uint32_t slot = atomicAdd(exc_count, 1u);
+            if (slot < exc_cap) { exc_rows[slot] = (uint32_t)i; exc_vals[slot] = v; }
+        }
+    }
+}
+
+__global__ void k_decode(const uint16_t *__restrict__ codes, uint64_t n, double *__restrict__ out,
+                         const double *__restrict__ table)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint16_t c = codes[i];
+        if (c != 0xFFFFu) out[i] = table[c];
+    }
+}
+
+__global__ void k_patch(double *__restrict__ out, const uint32_t *__restrict__ rows, const double *__restrict__ vals,
+                        uint32_t count, uint64_t row_base)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+        out[row_base + rows[i]] = vals[i];
+}
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);    \
+    } while (0)
+
+unsigned grid_for(uint64_t n)
+{
+    uint64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+} // namespace
+
+extern "C" {
+
+int strsim_codec_create(strsim_ctx_t *ctx, int measure, uint32_t max_chars, strsim_codec_t **out)
+{
+    if (!ctx || !out) { set_error("strsim_codec_create: NULL argument"); return STRSIM_ERR_ARG; }
+    *out = nullptr;
+    if (measure < 0 || measure >= STRSIM_NUM_MEASURES || max_chars == 0 || max_chars > 255) {
+        set_error("strsim_codec_create: bad measure/max_chars");
+        return STRSIM_ERR_ARG;
+    }
+    std::vector<double> vals;
+    enumerate_values(measure, max_chars, vals);
+    if (vals.size() >= 0xFFFFu) {
+        set_error("strsim_codec_create: %zu distinct values do not fit 16-bit codes (measure %d, max_chars %u)", vals.size(),
+                  measure, max_chars);
+        return STRSIM_ERR_ARG;
+    }
+    uint32_t hsize = 64;
+    while (hsize < 4 * vals.size()) hsize <<= 1;
+    std::vector<unsigned long long> keys(hsize, EMPTY_KEY);
+    std::vector<uint16_t> kvals(hsize, 0);
+    for (size_t i = 0; i < vals.size(); ++i) {
+        const unsigned long long b = bits_of(vals[i]);
+        uint32_t h = hash_bits(b) & (hsize - 1);
+        while (keys[h] != EMPTY_KEY) h = (h + 1) & (hsize - 1);
+        keys[h] = b;
+        kvals[h] = (uint16_t)i;
+    }
+    strsim_codec *c = new (std::nothrow) strsim_codec();
+    if (!c) { set_error("out of host memory"); return STRSIM_ERR_OOM; }
+    c->measure = measure; c->max_chars = max_chars; c->entries = (uint32_t)vals.size(); c->hash_mask = hsize - 1;
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    hipError_t e = hipMalloc((void **)&c->d_table, vals.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_keys, hsize * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_vals, hsize * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_table, vals.data(), vals.size() * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_keys, keys.data(), hsize * sizeof(unsigned long long), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_vals, kvals.data(), hsize * sizeof(uint16_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { strsim_codec_destroy(c); return hip_fail(e, "codec table upload"); }
+    *out = c;
+    return STRSIM_OK;
+}
+
+void strsim_codec_destroy(strsim_codec_t *c)
+{
+    if (!c) return;
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_vals) (void)hipFree(c->d_vals);
+    delete c;
+}
+
+uint32_t strsim_codec_entries(const strsim_codec_t *c) { return c ? c->entries : 0; }
+
+int strsim_codec_encode(strsim_ctx_t *ctx, const strsim_codec_t *c, const double *vals, uint64_t n, uint16_t *codes,
+                        uint32_t *exc_count, uint32_t *exc_rows, double *exc_vals, uint32_t exc_cap)
+{
+    if (!ctx || !c || (!vals && n) || (!codes && n) || !exc_count) { set_error("strsim_codec_encode: NULL argument"); return STRSIM_ERR_ARG; }
+    if (n >> 32) { set_error("strsim_codec_encode: more than 2^32 rows per call"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    HIP_TRY(hipMemsetAsync(exc_count, 0, sizeof(uint32_t), st));
+    if (n == 0) return STRSIM_OK;
+    hipLaunchKernelGGL(k_encode, dim3(grid_for(n)), dim3(256), 0, st, vals, n, codes, c->d_keys, c->d_vals, c->hash_mask,
+                       exc_count, exc_rows, exc_vals, exc_cap);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_codec_decode(strsim_ctx_t *ctx, const strsim_codec_t *c, const uint16_t *codes, uint64_t n, double *out)
+{
+    if (!ctx || !c || (!codes && n) || (!out && n)) { set_error("strsim_codec_decode: NULL argument"); return STRSIM_ERR_ARG; }
+    if (n == 0) return STRSIM_OK;
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    hipLaunchKernelGGL(k_decode, dim3(grid_for(n)), dim3(256), 0, st, codes, n, out, c->d_table);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_rows, const double *exc_vals,
+                       uint32_t count)
+{
+    if (!ctx || (count && (!out || !exc_rows || !exc_vals))) { set_error("strsim_codec_patch: NULL argument"); return STRSIM_ERR_ARG; }
+    if (count == 0) return STRSIM_OK;
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    hipLaunchKernelGGL(k_patch, dim3(grid_for(count)), dim3(256), 0, st, out, exc_rows, exc_vals, count, row_base);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+} // extern "C"

@@ -9,7 +9,7 @@ validity mask), as in README.md:69-70.
 import numpy as np
 
 from ._lib import MEASURES, MEASURE_ID, LIB_PATH, ShapeMismatch, StrsimError, lib
-from .context import Context, device_count, pack_strings, split_offsets
+from .context import Codec, Context, device_count, pack_strings, split_offsets
 
 _default_ctx = None
 
@@ -67,5 +67,5 @@ def sorensen_dice(a, b, ctx=None):
     return similarity("sorensen_dice", a, b, ctx)
 
 
-__all__ = ["Context", "device_count", "pack_strings", "split_offsets", "similarity", "levenshtein", "jaro",
+__all__ = ["Codec", "Context", "device_count", "pack_strings", "split_offsets", "similarity", "levenshtein", "jaro",
            "jaro_winkler", "jaccard", "sorensen_dice", "MEASURES", "MEASURE_ID", "ShapeMismatch", "StrsimError"]

@@ -59,6 +59,18 @@ def lib():
         f.argtypes = [vp, i32, vp, vp, u64, vp, vp, u64, vp, u64]
     L.strsim_pairs_device_all.restype = i32
     L.strsim_pairs_device_all.argtypes = [vp, vp, vp, u64, vp, vp, u64, C.POINTER(vp), u64]
+    L.strsim_codec_create.restype = i32
+    L.strsim_codec_create.argtypes = [vp, i32, C.c_uint32, C.POINTER(vp)]
+    L.strsim_codec_destroy.restype = None
+    L.strsim_codec_destroy.argtypes = [vp]
+    L.strsim_codec_entries.restype = C.c_uint32
+    L.strsim_codec_entries.argtypes = [vp]
+    L.strsim_codec_encode.restype = i32
+    L.strsim_codec_encode.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32]
+    L.strsim_codec_decode.restype = i32
+    L.strsim_codec_decode.argtypes = [vp, vp, vp, u64, vp]
+    L.strsim_codec_patch.restype = i32
+    L.strsim_codec_patch.argtypes = [vp, vp, u64, vp, vp, C.c_uint32]
     L.strsim_ctx_synchronize.restype = i32
     L.strsim_ctx_synchronize.argtypes = [vp]
     L.strsim_split_offsets.restype = None

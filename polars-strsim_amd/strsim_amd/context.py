@@ -117,6 +117,60 @@ class Context:
         return out
 
 
+class Codec:
+    """Lossless 16-bit transport codec for one measure's result column (include/strsim_amd.h: strsim_codec_*)."""
+    EXC_CAP = 1 << 20
+
+    def __init__(self, ctx, measure, max_chars=32):
+        import torch
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().strsim_codec_create(ctx._h, measure_id(measure), int(max_chars), C.byref(self._h)))
+        dev = torch.device("cuda", ctx.device)
+        self.exc_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.exc_rows = torch.empty(self.EXC_CAP, dtype=torch.int32, device=dev)
+        self.exc_vals = torch.empty(self.EXC_CAP, dtype=torch.float64, device=dev)
+
+    @property
+    def entries(self):
+        return int(lib().strsim_codec_entries(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().strsim_codec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, vals, codes=None, ctx=None):
+        """f64 tensor -> int16 tensor of codes (0xFFFF = exception, see exc_*); asynchronous on ctx's stream."""
+        import torch
+        ctx = ctx or self.ctx
+        if codes is None:
+            codes = torch.empty(vals.numel(), dtype=torch.int16, device=vals.device)
+        check(lib().strsim_codec_encode(ctx._h, self._h, vals.data_ptr(), vals.numel(), codes.data_ptr(),
+                                        self.exc_count.data_ptr(), self.exc_rows.data_ptr(), self.exc_vals.data_ptr(),
+                                        self.EXC_CAP))
+        return codes
+
+    def decode(self, codes, out=None, ctx=None):
+        import torch
+        ctx = ctx or self.ctx
+        if out is None:
+            out = torch.empty(codes.numel(), dtype=torch.float64, device=codes.device)
+        check(lib().strsim_codec_decode(ctx._h, self._h, codes.data_ptr(), codes.numel(), out.data_ptr()))
+        return out
+
+    def patch(self, out, row_base, exc_rows, exc_vals, count, ctx=None):
+        ctx = ctx or self.ctx
+        check(lib().strsim_codec_patch(ctx._h, out.data_ptr(), int(row_base), exc_rows.data_ptr(), exc_vals.data_ptr(),
+                                       int(count)))
+
+
 def pack_strings(strings):
     """list[str|bytes] -> (uint32 offsets[n+1], uint8 values): the device column layout."""
     bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strings]

@@ -219,3 +219,50 @@ def test_fused_all_measures_equals_single_measure_kernels(S):
         for m, o in zip(S.MEASURES, outs):
             exp = O.batch_strings(m, A, B, 8)
             assert_bit_exact(o.cpu().numpy(), exp, A, B, "fused " + m)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_transport_codec_round_trip(S, measure):
+    """16-bit codec: decode(encode(x)) == x bit for bit; rows with longer strings travel as exceptions."""
+    import torch
+    A, B = gen.pairs(81, 50000, gen.ASCII_LOWER, 0, 32, max_bytes=32)
+    A2, B2 = gen.pairs(82, 300, gen.ASCII_LOWER, 40, 120)   # outside the max_chars = 32 table (mostly)
+    A, B = A + A2, B + B2
+    ao, av = S.pack_strings(A)
+    bo, bv = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+        vals = ctx.pairs_device(measure, t(ao, np.int32), t(np.concatenate([av, pad]), np.uint8), t(bo, np.int32),
+                                t(np.concatenate([bv, pad]), np.uint8))
+        ctx.synchronize()
+        codec = S.Codec(ctx, measure, 32)
+        assert 300 < codec.entries < 65535
+        codes = codec.encode(vals)
+        out = torch.full_like(vals, -1.0)
+        codec.decode(codes, out)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        nexc = int(codec.exc_count.item())
+        exc = codes == -1  # 0xFFFF
+        assert int(exc.sum().item()) == nexc and 0 < nexc <= 300
+        assert bool((out[:50000].view(torch.int64) == vals[:50000].view(torch.int64)).all())
+        assert bool((out[exc] == -1.0).all())
+        codec.patch(out, 0, codec.exc_rows, codec.exc_vals, nexc)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int64), vals.view(torch.int64))
+        exp = O.batch_strings(measure, A, B, 8)
+        assert_bit_exact(out.cpu().numpy(), exp, A, B, "codec " + measure)
+        codec.close()
+
+
+def test_transport_codec_rejects_oversized_tables(S):
+    import torch
+    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+        with pytest.raises(S.StrsimError, match="do not fit 16-bit"):
+            S.Codec(ctx, "jaro_winkler", 128)
+        c = S.Codec(ctx, "levenshtein", 128)
+        assert c.entries > 1000
+        c.close()
