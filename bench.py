@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's row count)")
     p.add_argument("--measure", default="", help="override the config's measure")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the result shards")
+    p.add_argument("--no-codec", action="store_true", help="N>1: gather raw f64 instead of 16-bit codes")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the control flow)")
     p.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -128,50 +129,33 @@ def main():
     compute_stream = torch.cuda.current_stream()
     ctx = S.Context(local_rank, stream=compute_stream.cuda_stream)
     gather = world > 1 and not a.no_gather
-    comm_stream = torch.cuda.Stream() if gather else None
-    recv = None
-    host_gather = gather and a.backend != "nccl"  # gloo cannot gather device tensors: stage through the host (test mode)
-    if gather and rank == 0:
-        recv = torch.empty(world * rows, dtype=torch.float64, device="cpu" if host_gather else dev)
-    from strsim_amd.distributed import gather_column
-
-    pending = []
-
+    shipper = None
+    if gather:
+        from strsim_amd.distributed import ShardGatherer
+        # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
+        shipper = ShardGatherer(ctx, measures, rows, dev, backend=a.backend,
+                                codec_chars=32 if (hi <= 32 and not a.no_codec) else None)
     fused = len(measures) == 5  # cfg4: strsim_pairs_device_all, one fused pass with five outputs
 
     def step(i):
+        par = i & 1
+        os_ = out[par * len(measures):(par + 1) * len(measures)]
+        if gather:
+            for k in range(len(measures)):
+                shipper.wait_slot((par, k))  # the buffers about to be overwritten must have been shipped
         if fused:
-            if gather:
-                while len(pending) >= 5:
-                    pending.pop(0).wait()
-            os_ = out[(i & 1) * 5:(i & 1) * 5 + 5]
             ctx.pairs_device_all(offA, valA, offB, valB, outs=os_)
-            if gather:
-                comm_stream.wait_stream(compute_stream)
-                with torch.cuda.stream(comm_stream):
-                    for o in os_:
-                        src = o.cpu() if host_gather else o
-                        work, _ = gather_column(src, world * rows, dst=0, async_op=True, recv_buffer=recv)
-                        pending.append(work)
-            return
-        for k, m in enumerate(measures):
-            o = out[(i & 1) * len(measures) + k]
-            if gather and len(pending) >= 2 * len(measures):  # the buffer we are about to overwrite must have been sent
-                pending.pop(0).wait()
-            ctx.pairs_device(m, offA, valA, offB, valB, out=o)
-            if gather:
-                comm_stream.wait_stream(compute_stream)
-                with torch.cuda.stream(comm_stream):
-                    src = o.cpu() if host_gather else o
-                    work, _ = gather_column(src, world * rows, dst=0, async_op=True, recv_buffer=recv)
-                pending.append(work)
+        else:
+            for m, o in zip(measures, os_):
+                ctx.pairs_device(m, offA, valA, offB, valB, out=o)
+        if gather:
+            for k, (m, o) in enumerate(zip(measures, os_)):
+                shipper.submit((par, k), m, o)
 
     def drain():
-        while pending:
-            pending.pop(0).wait()
         ctx.synchronize()
-        if comm_stream is not None:
-            comm_stream.synchronize()
+        if shipper is not None:
+            shipper.drain()
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -193,10 +177,22 @@ def main():
     ctx.timing(False)
     wave_rows = ctx.last_wave_rows
 
+    gather_ok = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        cdev = dev if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if gather:
+            # outside the timed region: what rank 0 holds for the last shipped column must equal every rank's shard
+            last = out[((a.steps - 1) & 1) * len(measures) + len(measures) - 1]
+            mine = last.view(torch.int64).sum().reshape(1).to(cdev)
+            sums = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(sums, mine)
+            if rank == 0:
+                got = shipper.recv if not (shipper.host and not shipper.codecs) else shipper.recv_host.to(dev)
+                gather_ok = all(int(got[r * rows:(r + 1) * rows].view(torch.int64).sum().item()) == int(sums[r].item())
+                                for r in range(world))
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -225,6 +221,9 @@ def main():
             "config": {"workload": f"{a.config}: {measure}, {rows} rows per GPU, lengths "
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
                        "rows_per_gpu": rows, "gather_f64_to_rank0": bool(gather),
+                       "gather_transport": shipper.transport if shipper else None,
+                       "codec_exceptions": shipper.exceptions() if shipper else None,
+                       "gather_verified": gather_ok,
                        "rows_on_wave_kernel": wave_rows},
             "roofline": {"bound": "hbm", "kernel": "k_lane_pairs<%s>" % measures[0], "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -51,3 +51,83 @@ def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=
     if async_op:
         return work, finish
     return finish()
+
+
+class ShardGatherer:
+    """Ships every step's result shard(s) to rank 0 on a side stream, overlapped with the next step's kernels.
+
+    Transport is the raw f64 column, or -- when a Codec covers the measure (strings <= `codec_chars` characters) --
+    its lossless 16-bit code column, which rank 0 decodes back to f64 on the same side stream: 4x fewer bytes on the
+    one xGMI link each peer has into the root.  backend "nccl" (= RCCL) gathers device tensors; any other backend
+    stages through the host (only meant to smoke-test the control flow on one GPU).
+    """
+
+    def __init__(self, ctx, measures, rows, device, backend="nccl", codec_chars=None):
+        import strsim_amd as S
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.rows, self.dev, self.host = rows, device, backend != "nccl"
+        self.compute = torch.cuda.current_stream()
+        self.comm = torch.cuda.Stream()
+        self.ctx = ctx
+        self.ctx_comm = S.Context(ctx.device, stream=self.comm.cuda_stream)
+        self.codecs = {}
+        if codec_chars:
+            for m in measures:
+                try:
+                    self.codecs[m] = S.Codec(ctx, m, codec_chars)
+                except S.StrsimError:
+                    self.codecs = {}
+                    break
+        self.codes, self.done = {}, {}
+        n = self.world * rows
+        root = self.rank == 0
+        self.recv = torch.empty(n, dtype=torch.float64, device=device) if root else None
+        self.recv_codes = None
+        if self.codecs and root:  # codes travel as bytes: neither RCCL nor gloo has a 16-bit integer type
+            self.recv_codes = torch.empty(2 * n, dtype=torch.uint8, device="cpu" if self.host else device)
+        elif root and self.host:
+            self.recv_host = torch.empty(n, dtype=torch.float64)
+
+    @property
+    def transport(self):
+        return "u16 codes" if self.codecs else "f64"
+
+    def wait_slot(self, slot):
+        """Call before overwriting the output buffer of `slot` (any hashable): its previous shipment must be done."""
+        ev = self.done.get(slot)
+        if ev is not None:
+            self.compute.wait_event(ev)
+
+    def submit(self, slot, measure, out):
+        codec = self.codecs.get(measure)
+        src = out
+        if codec is not None:
+            buf = self.codes.get(slot)
+            if buf is None:
+                buf = self.codes[slot] = torch.empty(self.rows, dtype=torch.int16, device=self.dev)
+            src = codec.encode(out, buf)  # on the compute stream, right behind the kernels
+        self.comm.wait_stream(self.compute)
+        with torch.cuda.stream(self.comm):
+            if codec is not None:
+                raw = src.view(torch.uint8)
+                work, _ = gather_column(raw.cpu() if self.host else raw, 2 * self.world * self.rows, dst=0, async_op=True,
+                                        recv_buffer=self.recv_codes)
+                work.wait()
+                if self.rank == 0:
+                    rc = self.recv_codes.to(self.dev) if self.host else self.recv_codes
+                    codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_comm)
+            else:
+                work, _ = gather_column(src.cpu() if self.host else src, self.world * self.rows, dst=0, async_op=True,
+                                        recv_buffer=(self.recv_host if self.host else self.recv) if self.rank == 0 else None)
+                work.wait()
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+            self.done[slot] = ev
+
+    def drain(self):
+        self.comm.synchronize()
+        self.ctx_comm.synchronize()
+
+    def exceptions(self):
+        """Rows the codecs could not code in their LAST encode on this rank (must be 0 for the result to be complete)."""
+        return sum(int(c.exc_count.item()) for c in self.codecs.values())
