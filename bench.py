@@ -126,14 +126,16 @@ def main():
     offA, valA, offB, valB, bytesA, bytesB = W.device_columns(seed, law, lo, hi, rank * rows, rows, dev)
     out = [torch.empty(rows, dtype=torch.float64, device=dev) for _ in range(2 * len(measures))]
 
-    compute_stream = torch.cuda.current_stream()
+    compute_stream = torch.cuda.Stream()  # an explicit stream: handle 0 (the legacy default stream) would make the
+    torch.cuda.set_stream(compute_stream)  # context create its own, and torch-side waits would not see the kernels
     ctx = S.Context(local_rank, stream=compute_stream.cuda_stream)
+    assert ctx.stream == compute_stream.cuda_stream
     gather = world > 1 and not a.no_gather
     shipper = None
     if gather:
         from strsim_amd.distributed import ShardGatherer
         # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
-        shipper = ShardGatherer(ctx, measures, rows, dev, backend=a.backend,
+        shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend,
                                 codec_chars=32 if (hi <= 32 and not a.no_codec) else None)
     fused = len(measures) == 5  # cfg4: strsim_pairs_device_all, one fused pass with five outputs
 

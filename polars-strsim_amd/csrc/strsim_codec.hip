@@ -116,10 +116,28 @@ __global__ void k_encode(const double *__restrict__ vals, uint64_t n, uint16_t *
     }
 }
 
+// four rows per thread: one 8-byte load of codes, four table reads (L2-resident table), two 16-byte stores
 __global__ void k_decode(const uint16_t *__restrict__ codes, uint64_t n, double *__restrict__ out,
                          const double *__restrict__ table)
 {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t nq = n >> 2;
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 c4 = reinterpret_cast<const uint2 *>(codes)[q];
+        const uint32_t c0 = c4.x & 0xFFFFu, c1 = c4.x >> 16, c2 = c4.y & 0xFFFFu, c3 = c4.y >> 16;
+        double *o = out + 4 * q;
+        if ((c0 != 0xFFFFu) & (c1 != 0xFFFFu) & (c2 != 0xFFFFu) & (c3 != 0xFFFFu)) {
+            const double2 lo = {table[c0], table[c1]}, hi = {table[c2], table[c3]};
+            reinterpret_cast<double2 *>(o)[0] = lo;
+            reinterpret_cast<double2 *>(o)[1] = hi;
+        } else {
+            if (c0 != 0xFFFFu) o[0] = table[c0];
+            if (c1 != 0xFFFFu) o[1] = table[c1];
+            if (c2 != 0xFFFFu) o[2] = table[c2];
+            if (c3 != 0xFFFFu) o[3] = table[c3];
+        }
+    }
+    const uint64_t i = 4 * nq + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; // tail (< 4 rows)
+    if (i < n) {
         const uint16_t c = codes[i];
         if (c != 0xFFFFu) out[i] = table[c];
     }
@@ -220,7 +238,11 @@ int strsim_codec_decode(strsim_ctx_t *ctx, const strsim_codec_t *c, const uint16
     if (!ctx || !c || (!codes && n) || (!out && n)) { set_error("strsim_codec_decode: NULL argument"); return STRSIM_ERR_ARG; }
     if (n == 0) return STRSIM_OK;
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
-    hipLaunchKernelGGL(k_decode, dim3(grid_for(n)), dim3(256), 0, st, codes, n, out, c->d_table);
+    if ((reinterpret_cast<uintptr_t>(codes) & 7u) || (reinterpret_cast<uintptr_t>(out) & 15u)) {
+        set_error("strsim_codec_decode: codes must be 8-byte and out 16-byte aligned");
+        return STRSIM_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_decode, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, codes, n, out, c->d_table);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

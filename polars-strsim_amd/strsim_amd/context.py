@@ -22,7 +22,9 @@ class Context:
     """One GPU + one HIP stream + workspace (include/strsim_amd.h: strsim_ctx_t).  One per thread."""
 
     def __init__(self, device=0, stream=None):
-        """`stream`: an int hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None for an own stream."""
+        """`stream`: an int hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or None / 0 for an own non-blocking
+        stream.  Note that torch's default stream has handle 0: pass an explicit torch stream when torch-side
+        stream waits / events must order against this context's kernels."""
         self._h = C.c_void_p()
         check(lib().strsim_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = int(device)

@@ -62,14 +62,20 @@ class ShardGatherer:
     stages through the host (only meant to smoke-test the control flow on one GPU).
     """
 
-    def __init__(self, ctx, measures, rows, device, backend="nccl", codec_chars=None):
+    def __init__(self, ctx, compute_stream, measures, rows, device, backend="nccl", codec_chars=None):
+        """`compute_stream`: the torch stream whose handle `ctx` was created with (the kernels' stream)."""
         import strsim_amd as S
+        if ctx.stream != compute_stream.cuda_stream:
+            raise ValueError("ShardGatherer: ctx does not enqueue on compute_stream")
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.rows, self.dev, self.host = rows, device, backend != "nccl"
-        self.compute = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream()
+        self.compute = compute_stream
+        self.comm = torch.cuda.Stream()    # encode + gather
+        self.decode = torch.cuda.Stream()  # root only: decode of step i overlaps the gather of step i+1
         self.ctx = ctx
         self.ctx_comm = S.Context(ctx.device, stream=self.comm.cuda_stream)
+        self.ctx_decode = S.Context(ctx.device, stream=self.decode.cuda_stream)
+        self.nsub = 0
         self.codecs = {}
         if codec_chars:
             for m in measures:
@@ -83,8 +89,9 @@ class ShardGatherer:
         root = self.rank == 0
         self.recv = torch.empty(n, dtype=torch.float64, device=device) if root else None
         self.recv_codes = None
+        self.decoded = [None, None]
         if self.codecs and root:  # codes travel as bytes: neither RCCL nor gloo has a 16-bit integer type
-            self.recv_codes = torch.empty(2 * n, dtype=torch.uint8, device="cpu" if self.host else device)
+            self.recv_codes = [torch.empty(2 * n, dtype=torch.uint8, device="cpu" if self.host else device) for _ in range(2)]
         elif root and self.host:
             self.recv_host = torch.empty(n, dtype=torch.float64)
 
@@ -101,21 +108,31 @@ class ShardGatherer:
     def submit(self, slot, measure, out):
         codec = self.codecs.get(measure)
         src = out
-        if codec is not None:
-            buf = self.codes.get(slot)
-            if buf is None:
-                buf = self.codes[slot] = torch.empty(self.rows, dtype=torch.int16, device=self.dev)
-            src = codec.encode(out, buf)  # on the compute stream, right behind the kernels
         self.comm.wait_stream(self.compute)
         with torch.cuda.stream(self.comm):
             if codec is not None:
+                buf = self.codes.get(slot)
+                if buf is None:
+                    buf = self.codes[slot] = torch.empty(self.rows, dtype=torch.int16, device=self.dev)
+                # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's
+                # VALU-bound kernels
+                src = codec.encode(out, buf, ctx=self.ctx_comm)
+            if codec is not None:
                 raw = src.view(torch.uint8)
+                b = self.nsub & 1
+                self.nsub += 1
+                if self.rank == 0 and self.decoded[b] is not None:
+                    self.comm.wait_event(self.decoded[b])  # the decode that last read this receive buffer
                 work, _ = gather_column(raw.cpu() if self.host else raw, 2 * self.world * self.rows, dst=0, async_op=True,
-                                        recv_buffer=self.recv_codes)
+                                        recv_buffer=self.recv_codes[b] if self.rank == 0 else None)
                 work.wait()
                 if self.rank == 0:
-                    rc = self.recv_codes.to(self.dev) if self.host else self.recv_codes
-                    codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_comm)
+                    self.decode.wait_stream(self.comm)
+                    with torch.cuda.stream(self.decode):
+                        rc = self.recv_codes[b].to(self.dev) if self.host else self.recv_codes[b]
+                        codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_decode)
+                        self.decoded[b] = torch.cuda.Event()
+                        self.decoded[b].record(self.decode)
             else:
                 work, _ = gather_column(src.cpu() if self.host else src, self.world * self.rows, dst=0, async_op=True,
                                         recv_buffer=(self.recv_host if self.host else self.recv) if self.rank == 0 else None)
@@ -127,6 +144,8 @@ class ShardGatherer:
     def drain(self):
         self.comm.synchronize()
         self.ctx_comm.synchronize()
+        self.decode.synchronize()
+        self.ctx_decode.synchronize()
 
     def exceptions(self):
         """Rows the codecs could not code in their LAST encode on this rank (must be 0 for the result to be complete)."""
