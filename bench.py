@@ -122,8 +122,20 @@ def main():
     rows = a.rows or cfg[1]
     _, _, law, lo, hi, seed = cfg
 
-    # rank r holds rows [r*rows, (r+1)*rows) of the (world*rows)-row frame
-    offA, valA, offB, valB, bytesA, bytesB = W.device_columns(seed, law, lo, hi, rank * rows, rows, dev)
+    # rank r holds rows [r*rows, (r+1)*rows) of the (world*rows)-row frame; a shard whose packed values would not fit
+    # 32-bit offsets (cfg5: ~5 GB per column) is held as several row batches, each its own offsets+values pair
+    mean_len = (lo + hi) / 2.0 if law == W.UNIFORM else 26.0
+    nparts = max(1, int(rows * mean_len * 1.15 / 3.5e9) + (1 if rows * mean_len * 1.15 > 3.5e9 else 0))
+    bounds = [rows * p // nparts for p in range(nparts + 1)]
+    parts = []
+    bytesA = bytesB = 0
+    for p in range(nparts):
+        r0, r1 = bounds[p], bounds[p + 1]
+        oa, va, ob, vb, ba, bb = W.device_columns(seed, law, lo, hi, rank * rows + r0, r1 - r0, dev)
+        parts.append((r0, r1, oa, va, ob, vb))
+        bytesA += ba
+        bytesB += bb
+    offA, valA, offB, valB = parts[0][2:6]
     out = [torch.empty(rows, dtype=torch.float64, device=dev) for _ in range(2 * len(measures))]
 
     compute_stream = torch.cuda.Stream()  # an explicit stream: handle 0 (the legacy default stream) would make the
@@ -145,11 +157,12 @@ def main():
         if gather:
             for k in range(len(measures)):
                 shipper.wait_slot((par, k))  # the buffers about to be overwritten must have been shipped
-        if fused:
-            ctx.pairs_device_all(offA, valA, offB, valB, outs=os_)
-        else:
-            for m, o in zip(measures, os_):
-                ctx.pairs_device(m, offA, valA, offB, valB, out=o)
+        for r0, r1, oa, va, ob, vb in parts:
+            if fused:
+                ctx.pairs_device_all(oa, va, ob, vb, outs=[o[r0:r1] for o in os_])
+            else:
+                for m, o in zip(measures, os_):
+                    ctx.pairs_device(m, oa, va, ob, vb, out=o[r0:r1])
         if gather:
             for k, (m, o) in enumerate(zip(measures, os_)):
                 shipper.submit((par, k), m, o)
@@ -199,10 +212,10 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * rows * a.steps / dt / 1e6
-        read_bytes = bytesA + bytesB + 2 * 4 * (rows + 1)   # each byte/offset counted once
+        read_bytes = bytesA + bytesB + 2 * 4 * (rows + nparts)   # each byte/offset counted once
         write_bytes = 8 * rows
-        lane_ms = tm["lane_ms"] / max(tm["lane_launches"], 1)
-        wave_ms = tm["wave_ms"] / max(tm["wave_launches"], 1)
+        lane_ms = tm["lane_ms"] / max(tm["lane_launches"], 1) * nparts   # per pass over the whole shard
+        wave_ms = tm["wave_ms"] / max(tm["wave_launches"], 1) * nparts
         # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc run of this same command
         # (bench_support/profile.sh -> profiles/traffic.json; FETCH_SIZE doubled per the gfx950 note)
         traffic = None
@@ -234,9 +247,9 @@ def main():
                          "achieved_read_plus_write": (read_bytes + write_bytes) / (lane_ms * 1e-3) / 1e9 if lane_ms > 0 else 0.0},
         }
         if a.config == "cfg5" or hi > 128:
-            la_ = (offA[1:] - offA[:-1]).to(torch.float64)
-            lb_ = (offB[1:] - offB[:-1]).to(torch.float64)
-            cells = float((la_ * lb_).sum().item())
+            cells = 0.0
+            for _r0, _r1, oa, _va, ob, _vb in parts:
+                cells += float(((oa[1:] - oa[:-1]).to(torch.float64) * (ob[1:] - ob[:-1]).to(torch.float64)).sum().item())
             res["gcups"] = cells * len(measures) * a.steps / dt / 1e9  # DP cells per second (compute-bound workloads)
         if not a.no_e2e and world == 1 and len(measures) == 1:
             try:
