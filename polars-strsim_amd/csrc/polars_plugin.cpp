@@ -26,6 +26,8 @@
 #include <string>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -33,6 +35,7 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include "polars_plugin_abi.h"
 #include "strsim_amd.h"
@@ -268,25 +271,100 @@ void release_series(SeriesExport *e)
 void *alloc64(size_t bytes)
 {
     void *p = nullptr;
-    if (posix_memalign(&p, 64, bytes ? ((bytes + 63) & ~size_t(63)) : 64) != 0) throw std::bad_alloc();
+    const bool big = bytes >= (size_t(8) << 20);
+    // large result columns: 2 MiB alignment + transparent huge pages, so first-touch faults do not dominate the
+    // final copy (80 MB = 20 000 4-KiB faults otherwise)
+    const size_t align = big ? (size_t(2) << 20) : 64;
+    const size_t size = bytes ? ((bytes + align - 1) & ~(align - 1)) : 64;
+    if (posix_memalign(&p, align, size) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+    if (big) (void)madvise(p, size, MADV_HUGEPAGE);
+#endif
     return p;
 }
 
-// ---- a tiny fork-join helper for the host-side packing ------------------------------------------------
-void fork_join(unsigned nthreads, const std::function<void(unsigned)> &fn)
-{
-    if (nthreads <= 1) { fn(0); return; }
-    std::vector<std::thread> th;
-    std::vector<std::string> errs(nthreads);
-    th.reserve(nthreads - 1);
-    auto body = [&](unsigned t) {
-        try { fn(t); } catch (const PluginError &e) { errs[t] = e.msg; } catch (...) { errs[t] = "unexpected failure in a packing thread"; }
-    };
-    for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(body, t);
-    body(0);
-    for (auto &x : th) x.join();
-    for (auto &e : errs) if (!e.empty()) fail(e);
-}
+// ---- a small persistent fork-join pool for the host-side packing (one per calling thread) ------------------
+class ForkJoinPool {
+  public:
+    ~ForkJoinPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // run fn(0 .. n-1), fn(0) on the caller; rethrows the first failure as a PluginError
+    void run(unsigned n, const std::function<void(unsigned)> &fn)
+    {
+        if (n <= 1) { fn(0); return; }
+        while (th_.size() + 1 < n) {
+            const unsigned id = (unsigned)th_.size() + 1;
+            th_.emplace_back([this, id] { worker(id); });
+        }
+        err_.clear();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            njob_ = n;
+            pending_ = n - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        call(fn, 0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+        if (!err_.empty()) fail(err_);
+    }
+
+  private:
+    void call(const std::function<void(unsigned)> &fn, unsigned t)
+    {
+        try {
+            fn(t);
+        } catch (const PluginError &e) {
+            std::lock_guard<std::mutex> lk(m_);
+            if (err_.empty()) err_ = e.msg;
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(m_);
+            if (err_.empty()) err_ = "unexpected failure in a packing thread";
+        }
+    }
+    void worker(unsigned id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (id >= njob_) continue;
+                job = job_;
+            }
+            call(*job, id);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                --pending_;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned njob_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    std::string err_;
+};
+thread_local ForkJoinPool g_pool;
+
+void fork_join(unsigned nthreads, const std::function<void(unsigned)> &fn) { g_pool.run(nthreads, fn); }
 
 #define HIP_OR_FAIL(expr)                                                                           \
     do {                                                                                            \
@@ -359,18 +437,18 @@ constexpr uint64_t SLICE_BYTES = (1ull << 32) - (1ull << 24);  // packed values 
 unsigned pack_threads(bool engine_parallel, uint64_t rows)
 {
     // CallerContext PARALLEL (reference strsim.rs:53): the engine is already parallel -> no helper threads here
-    if (engine_parallel || rows < 200000) return 1;
+    if (engine_parallel || rows < 32768) return 1;
     unsigned hw = std::thread::hardware_concurrency();
     if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) hw = (unsigned)atoi(e);
     if (hw == 0) hw = 1;
-    return std::min<unsigned>(hw, 32u);
+    return (unsigned)std::min<uint64_t>(std::min<unsigned>(hw, 32u), rows / 16384);
 }
 
 // pack rows [r0, r1) of `c` into pinned staging (u32 offsets rebased to 0); returns the packed byte count
 uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &val, unsigned T)
 {
     const uint64_t rows = r1 - r0;
-    T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(rows / 65536, 1));
+    T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(rows / 16384, 1));
     std::vector<uint64_t> part(T + 1, 0);
     auto lo = [&](unsigned t) { return r0 + rows * t / T; };
     fork_join(T, [&](unsigned t) { part[t + 1] = range_bytes(c, lo(t), lo(t + 1)); });
@@ -385,8 +463,19 @@ uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &va
     return total;
 }
 
+struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin call on stderr
+    bool on;
+    double t_pack = 0, t_wait = 0, t_d2h = 0, t_copy = 0, t_launch = 0;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(getenv("POLARS_STRSIM_TRACE") != nullptr) {}
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void stop(double &acc) { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)
 {
+    PhaseTimer tm;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (n_inputs != 2) fail("expected 2 input series, got " + std::to_string(n_inputs));
     Column col[2];
     describe(inputs[0], col[0]);
@@ -468,26 +557,32 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
                 fail(strsim_last_error_message());
         };
         auto finish = [&](Slot &sl) {
+            tm.start();
             if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+            tm.stop(tm.t_wait);
+            tm.start();
             HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIP_OR_FAIL(hipStreamSynchronize(stream));
+            tm.stop(tm.t_d2h);
+            tm.start();
             const double *src = static_cast<const double *>(sl.h_out.p);
             const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
             fork_join(Tc, [&](unsigned t) {
                 const uint64_t i0 = sl.rows * t / Tc, i1 = sl.rows * (t + 1) / Tc;
                 memcpy(out + sl.r0 + i0, src + i0, (i1 - i0) * sizeof(double));
             });
+            tm.stop(tm.t_copy);
         };
 
         uint64_t r0 = 0;
         int cur = 0;
-        r0 += pack(g_ctx.slot[cur], r0, SLICE_ROWS);
-        launch(g_ctx.slot[cur]);
+        tm.start(); r0 += pack(g_ctx.slot[cur], r0, SLICE_ROWS); tm.stop(tm.t_pack);
+        tm.start(); launch(g_ctx.slot[cur]); tm.stop(tm.t_launch);
         while (r0 < n) {
             const int nxt = cur ^ 1;
-            r0 += pack(g_ctx.slot[nxt], r0, SLICE_ROWS); // overlaps the GPU work of slot `cur`
+            tm.start(); r0 += pack(g_ctx.slot[nxt], r0, SLICE_ROWS); tm.stop(tm.t_pack); // overlaps the GPU work of slot `cur`
             finish(g_ctx.slot[cur]);
-            launch(g_ctx.slot[nxt]);
+            tm.start(); launch(g_ctx.slot[nxt]); tm.stop(tm.t_launch);
             cur = nxt;
         }
         finish(g_ctx.slot[cur]);
@@ -536,6 +631,11 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     ret->len = 1;
     ret->release = release_series;
     ret->private_data = sp;
+    if (tm.on)
+        fprintf(stderr, "[polars_strsim] rows=%llu total=%.2f ms: pack=%.2f launch=%.2f wait=%.2f d2h=%.2f copy=%.2f\n",
+                (unsigned long long)n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), tm.t_pack,
+                tm.t_launch, tm.t_wait, tm.t_d2h, tm.t_copy);
 }
 
 void plugin_entry(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, const CallerContext *cc)
