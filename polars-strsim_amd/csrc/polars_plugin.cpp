@@ -438,10 +438,9 @@ unsigned pack_threads(bool engine_parallel, uint64_t rows)
 {
     // CallerContext PARALLEL (reference strsim.rs:53): the engine is already parallel -> no helper threads here
     if (engine_parallel || rows < 32768) return 1;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) hw = (unsigned)atoi(e);
-    if (hw == 0) hw = 1;
-    return (unsigned)std::min<uint64_t>(std::min<unsigned>(hw, 32u), rows / 16384);
+    unsigned cap = std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 1u), 32u);
+    if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) cap = std::max(1, atoi(e)); // explicit override, any value
+    return (unsigned)std::min<uint64_t>(cap, rows / 16384);
 }
 
 // pack rows [r0, r1) of `c` into pinned staging (u32 offsets rebased to 0); returns the packed byte count
