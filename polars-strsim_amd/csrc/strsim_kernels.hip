@@ -3,19 +3,20 @@
 //
 // Device data layout (per column shard): uint32 offsets[rows+1] + packed UTF-8 bytes; output f64[n].
 //
-// Two kernel families, both launched for every call:
+// Kernels, chained through one 64-bit "not finished yet" mask per 64 rows:
 //
-//   k_lane_pairs<M>   ONE PAIR PER LANE.  A wave takes 64 consecutive rows; each lane pulls its two
-//                     strings (<= 32 bytes each, ASCII) into 2 x 8 VGPRs with unaligned 16-byte
-//                     loads (adjacent lanes read adjacent strings, so the wave's loads cover one
-//                     contiguous ~1 KiB span per column), transposes b into bit-planes and runs the
-//                     bit-parallel cores of strsim_lane_core.h entirely in registers -- no LDS, so
-//                     occupancy is bounded by VGPRs only.  Rows that do not fit (longer than 32 bytes
-//                     or non-ASCII) are recorded in a 64-bit mask per 64-row chunk.
-//   k_wave_pairs<M>   ONE PAIR PER WAVE for the rows recorded in those masks: both strings are decoded
-//                     to Unicode scalar values in LDS (the reference works on `char`s,
-//                     strsim.rs:133,189,297) and processed with wave-wide anti-diagonal DP / ballot
-//                     matching.  Handles strings up to WAVE_CAP bytes.
+//   k_lane_pairs<M>   ONE PAIR PER LANE, strings <= 32 ASCII bytes (the dominant kernel).  A 256-thread workgroup
+//                     takes 512 consecutive rows, buckets them by DP column count and runs them as 8 rounds of 64
+//                     rows of similar length; each lane pulls its two strings into 2 x 8 VGPRs with unaligned
+//                     16-byte loads, transposes one of them into bit-planes and runs the bit-parallel cores of
+//                     strsim_lane_core.h entirely in registers.  M = 5 is the fused five-output instantiation.
+//   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with 2- or 4-word masks
+//                     (strsim_lane_wide.h), text in an LDS column per lane.
+//   k_wave_pairs<M>   ONE PAIR PER WAVE (TWO for ASCII Levenshtein) for the rest, up to WAVE_CAP bytes, any UTF-8:
+//                     strings decoded to Unicode scalar values in LDS (the reference works on `char`s,
+//                     strsim.rs:133,189,297); block-parallel Myers across lanes / anti-diagonal DP / ballot matching.
+//   k_huge_pairs<M>   the same per-row code with its scratch in global memory, for strings beyond WAVE_CAP;
+//                     launched from strsim_ctx_synchronize() only when such rows were counted.
 //
 // No MFMA anywhere: this is integer/byte work whose roofline is HBM bytes.
 // Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
