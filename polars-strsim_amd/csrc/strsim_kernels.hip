@@ -12,6 +12,8 @@
 //                     strsim_lane_core.h entirely in registers.  M = 5 is the fused five-output instantiation.
 //   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with 2- or 4-word masks
 //                     (strsim_lane_wide.h), text in an LDS column per lane.
+//   k_lane_utf8<M>    ONE PAIR PER LANE, short non-ASCII strings (<= 32 scalar values, BMP): per-lane UTF-8 decode
+//                     into 16-bit symbols in LDS, then the same cores on symbols (strsim_lane_sym.h).
 //   k_wave_pairs<M>   ONE PAIR PER WAVE (TWO for ASCII Levenshtein) for the rest, up to WAVE_CAP bytes, any UTF-8:
 //                     strings decoded to Unicode scalar values in LDS (the reference works on `char`s,
 //                     strsim.rs:133,189,297); block-parallel Myers across lanes / anti-diagonal DP / ballot matching.
@@ -25,6 +27,7 @@
 
 #include "strsim_lane_core.h"
 #include "strsim_lane_wide.h"
+#include "strsim_lane_sym.h"
 #include "strsim_kernels.h"
 
 namespace strsim {
@@ -457,6 +460,154 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
                 else
                     wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
                 if (done) {
+                    out[row] = res;
+                    atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
+                }
+            }
+            __syncthreads();
+            if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
+        }
+        __syncthreads();
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lane_utf8: one pair per lane for short NON-ASCII strings -- both strings <= 128 bytes and, once decoded,
+// <= 32 Unicode scalar values, all in the BMP (names and words in any script).  Each lane decodes its two strings
+// from registers into 16-bit symbols in LDS columns and runs the up-to-16-plane cores of strsim_lane_sym.h.
+// Same span / collect / 64-row-round structure as k_lane_wide; rows it cannot take (longer, astral, empty side)
+// stay in the mask for k_wave_pairs.  Without it every non-ASCII row costs a whole wave (~500x slower).
+// ------------------------------------------------------------------------------------------------
+constexpr int U8_DW = 32; // 128-byte window per string
+
+struct LdsSym {
+    const uint16_t *col; // &s_sym[wave][0][lane]; symbol k at col[k * 64]
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return col[(k & 31u) * 64u]; }
+};
+struct LdsSymEmit {
+    uint16_t *col;
+    __device__ __forceinline__ void operator()(uint32_t k, uint32_t cp) const { if (k < 32u) col[k * 64u] = (uint16_t)cp; }
+};
+
+template <int MEASURE>
+__global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__restrict__ offA,
+                                                          const uint8_t *__restrict__ valA, uint64_t rowsA,
+                                                          const uint32_t *__restrict__ offB,
+                                                          const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                          double *__restrict__ out, uint64_t n,
+                                                          unsigned long long *__restrict__ slowmask)
+{
+    __shared__ unsigned long long s_mask[WIDE_SPAN];
+    __shared__ uint32_t s_cnt[8];
+    __shared__ uint16_t s_list[WIDE_ROWS];
+    __shared__ uint16_t s_symA[WIDE_WAVES][32][64];
+    __shared__ uint16_t s_symB[WIDE_WAVES][32][64];
+
+    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
+    constexpr int RPT = WIDE_ROWS / WIDE_BLOCK;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
+    const uint64_t nchunks = (n + 63u) >> 6;
+    const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
+    constexpr int SPANS_PER_SUPER = WIDE_BLOCK / WIDE_SPAN;
+    const uint64_t nsuper = (nspans + SPANS_PER_SUPER - 1) / SPANS_PER_SUPER;
+
+    for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+      const uint64_t cw = sup * WIDE_BLOCK + tid;
+      const unsigned long long myword = cw < nchunks ? slowmask[cw] : 0ull;
+      if (!__syncthreads_or(myword != 0ull)) continue;
+      for (uint64_t span = sup * SPANS_PER_SUPER; span < (sup + 1) * SPANS_PER_SUPER && span < nspans; ++span) {
+        const uint64_t c0 = span * WIDE_SPAN;
+        if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
+        if (tid < 8u) s_cnt[tid] = 0u;
+        __syncthreads();
+        const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
+        if (any) {
+            uint32_t key[RPT], rank[RPT];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const uint32_t i = k * WIDE_BLOCK + tid;
+                key[k] = 0xFFFFFFFFu;
+                if ((s_mask[i >> 6] >> (i & 63u)) & 1ull) {
+                    const uint64_t row = c0 * 64u + i;
+                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                    const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
+                    const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
+                    if (mx <= 128u && mx >= 1u) { // an empty side is fine here: the result is 0.0 without any DP
+                        (void)mn;
+                        key[k] = (mx - 1u) >> 4; // similar byte lengths together
+                        rank[k] = atomicAdd(&s_cnt[key[k]], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            uint32_t total = 0;
+            {
+                uint32_t c[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c[q] = s_cnt[q]; total += c[q]; }
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    if (key[k] == 0xFFFFFFFFu) continue;
+                    uint32_t base = 0;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) base += ((uint32_t)q < key[k]) ? c[q] : 0u;
+                    s_list[base + rank[k]] = (uint16_t)(k * WIDE_BLOCK + tid);
+                }
+            }
+            __syncthreads();
+            const uint32_t nrounds = (total + 63u) >> 6;
+            for (uint32_t rr = wv; rr < nrounds; rr += WIDE_WAVES) {
+                const uint32_t r = nrounds - 1u - rr;
+                const uint32_t li = r * 64u + lane;
+                const bool has = li < total;
+                const uint32_t i = has ? s_list[li] : 0u;
+                const uint64_t row = c0 * 64u + i;
+                uint32_t a0 = 0, la8 = 0, b0 = 0, lb8 = 0;
+                if (has) {
+                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                    a0 = offA[ra]; la8 = offA[ra + 1] - a0;
+                    b0 = offB[rb]; lb8 = offB[rb + 1] - b0;
+                }
+                uint16_t *colA = &s_symA[wv][0][lane], *colB = &s_symB[wv][0][lane];
+                bool big = false;
+                uint32_t ov = 0u, av = 0xFFFFFFFFu;
+                uint32_t la, lb;
+                {
+                    uint32_t w[U8_DW];
+#pragma unroll
+                    for (int d = 0; d < U8_DW; ++d) w[d] = 0u;
+                    if (has) load_window_any<U8_DW>(valA, (int64_t)a0, totalA, w);
+                    la = utf8_decode_lane<U8_DW>(w, la8, (wave_max_u8(la8) + 3u) >> 2, LdsSymEmit{colA}, big, ov, av);
+                }
+                {
+                    uint32_t w[U8_DW];
+#pragma unroll
+                    for (int d = 0; d < U8_DW; ++d) w[d] = 0u;
+                    if (has) load_window_any<U8_DW>(valB, (int64_t)b0, totalB, w);
+                    lb = utf8_decode_lane<U8_DW>(w, lb8, (wave_max_u8(lb8) + 3u) >> 2, LdsSymEmit{colB}, big, ov, av);
+                }
+                const bool empty = has && (la8 == 0u || lb8 == 0u); // exactly one side empty (both-empty rows never get here)
+                const bool ok = has && !empty && !big && la <= 32u && lb <= 32u;
+                if (empty) {
+                    out[row] = 0.0; // strsim.rs:184-186, :290-292, :326-328; Levenshtein: 1 - max/max (:160)
+                    atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
+                }
+                if (__ballot(ok) == 0ull) continue;
+                const bool swap = SYMMETRIC && la > lb; // symmetric measures walk the shorter string
+                const uint16_t *tcol = swap ? colB : colA, *pcol = swap ? colA : colB;
+                const uint32_t lt = ok ? (swap ? lb : la) : 1u, lp = ok ? (swap ? la : lb) : 1u;
+                const uint32_t steps = wave_max_u8(ok ? lt : 0u);
+                const uint32_t vary = (ov ^ av) & 0xFFFFu;
+                const bool need16 = __ballot(ok && (vary >> 11)) != 0ull;
+                const bool need11 = __ballot(ok && (vary >> 8)) != 0ull;
+                double res;
+                if (need16) res = lane_sym_result<MEASURE, 16>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
+                else if (need11) res = lane_sym_result<MEASURE, 11>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
+                else res = lane_sym_result<MEASURE, 8>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
+                if (ok) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
@@ -977,6 +1128,8 @@ static void launch_pair(const LaunchArgs &a)
         const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
         hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
+        hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status);
@@ -1011,6 +1164,8 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
     const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
     const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
     hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask);
+    hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask, a.status);

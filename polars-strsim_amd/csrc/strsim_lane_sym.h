@@ -1,0 +1,189 @@
+// strsim_lane_sym.h -- per-lane cores for short NON-ASCII strings: up to 32 Unicode scalar values per string,
+// every one of them in the Basic Multilingual Plane (<= 0xFFFF), i.e. names and words in any script.
+//
+// The reference compares `char`s, not bytes (strsim.rs:133,189,297), so each lane first decodes its two UTF-8
+// strings (<= 128 bytes, in registers) into 16-bit symbols stored in an LDS column per lane; from there the cores
+// are the bit-sliced ones of strsim_lane_core.h with up to 16 bit-planes per pattern instead of 7:
+//     Eq(sym) = valid & AND_k ~(P_k ^ bit_k(sym)),   k over the bits that vary inside the pair.
+// Host/device portable (the CPU harness in tests/ runs the same code).
+#pragma once
+#include "strsim_lane_core.h"
+
+namespace strsim {
+
+// ---------------------------------------------------------------------------------------------
+// `str::chars()` for one lane: walk the first len8 bytes of the 32*NW-byte window w[], call emit(k, cp) for the k-th
+// scalar value.  nd4 = number of dwords to walk (lane-uniform bound >= ceil(len8 / 4)).  Valid UTF-8 only.
+// Returns the number of scalar values; `big` is set when one exceeds 0xFFFF, `ovar`/`avar` accumulate OR / AND of
+// the emitted values (for the plane-count choice).
+// ---------------------------------------------------------------------------------------------
+template <int NDW, class Emit>
+STRSIM_HD uint32_t utf8_decode_lane(const uint32_t (&w)[NDW], uint32_t len8, uint32_t nd4, const Emit &emit, bool &big,
+                                    uint32_t &ovar, uint32_t &avar)
+{
+    uint32_t k = 0;       // scalar values emitted so far
+    uint32_t cp = 0;      // value being assembled
+    bool open = false;    // a value is being assembled
+#pragma unroll
+    for (int d = 0; d < NDW; ++d) {
+        if ((uint32_t)d >= nd4) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t p = 4u * (uint32_t)d + (uint32_t)q;
+            const uint32_t b = (w[d] >> (8 * q)) & 0xFFu;
+            if (p < len8) {
+                if ((b & 0xC0u) == 0x80u) {
+                    cp = (cp << 6) | (b & 0x3Fu);
+                } else {
+                    if (open) {
+                        emit(k, cp);
+                        big = big || cp > 0xFFFFu;
+                        ovar |= cp; avar &= cp;
+                        ++k;
+                    }
+                    open = true;
+                    cp = b < 0x80u ? b : (b < 0xE0u ? (b & 0x1Fu) : (b < 0xF0u ? (b & 0x0Fu) : (b & 0x07u)));
+                }
+            }
+        }
+    }
+    if (open) {
+        emit(k, cp);
+        big = big || cp > 0xFFFFu;
+        ovar |= cp; avar &= cp;
+        ++k;
+    }
+    return k;
+}
+
+// planes 0..NP-1 (NP <= 16) of up to 32 16-bit symbols; sym(k) returns symbol k (k < 32; don't-care past the length)
+template <int NP, class Sym>
+STRSIM_HD void build_planes_sym(const Sym &sym, uint32_t (&P)[NP])
+{
+    uint32_t lo[8], hi[8]; // low bytes / high bytes of the 32 symbols, packed 4 per dword
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const uint32_t s0 = sym(4 * g), s1 = sym(4 * g + 1), s2 = sym(4 * g + 2), s3 = sym(4 * g + 3);
+        lo[g] = (s0 & 0xFFu) | ((s1 & 0xFFu) << 8) | ((s2 & 0xFFu) << 16) | ((s3 & 0xFFu) << 24);
+        hi[g] = ((s0 >> 8) & 0xFFu) | (((s1 >> 8) & 0xFFu) << 8) | (((s2 >> 8) & 0xFFu) << 16) | (((s3 >> 8) & 0xFFu) << 24);
+    }
+    constexpr int NLO = NP < 8 ? NP : 8;
+    uint32_t plo[NLO];
+    build_planes<NLO>(lo, plo);
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) P[k] = plo[k];
+    if (NP > 8) {
+        constexpr int NHI = NP > 8 ? NP - 8 : 1;
+        uint32_t phi[NHI];
+        build_planes<NHI>(hi, phi);
+#pragma unroll
+        for (int k = 0; k < NHI; ++k) P[(8 + k) < NP ? (8 + k) : 0] = phi[k];
+    }
+}
+
+template <int NP>
+STRSIM_HD uint32_t eq_sym(const uint32_t (&P)[NP], uint32_t valid, uint32_t s)
+{
+    uint32_t acc = valid;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) acc = bitop3<0x90>(acc, P[k], bit_fill(s, k));
+    return acc;
+}
+
+// number of planes needed: position of the highest varying bit + 1, rounded to the instantiated sizes
+STRSIM_HD int planes_needed_sym(uint32_t vary) { return (vary >> 11) ? 16 : ((vary >> 8) ? 11 : 8); }
+
+// ---- the three cores; text symbols through txt(j), steps = lane-uniform loop bound >= lt -----------------
+template <int NP, class Txt>
+STRSIM_HD uint32_t lev_sym(const Txt &txt, uint32_t lt, uint32_t steps, const uint32_t (&P)[NP], uint32_t lp)
+{
+    const uint32_t s = 32u - lp;
+    const uint32_t valid = 0xFFFFFFFFu << s;
+    uint32_t Pv = valid, Mv = ~Pv, hp = 0u, hn = 0u;
+    for (uint32_t j = 0; j < steps; ++j) {
+        const uint32_t Eq = eq_sym<NP>(P, valid, txt(j));
+        const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq | Mv);
+        const uint32_t HP = bitop3<0xF1>(Mv, D0, Pv);
+        const uint32_t HN = Pv & D0;
+        hp = (hp << 1) | (HP >> 31);
+        hn = (hn << 1) | (HN >> 31);
+        const uint32_t X = (HP << 1) | 1u;
+        Pv = bitop3<0xF1>(HN << 1, D0, X);
+        Mv = D0 & X;
+    }
+    const uint32_t cols = low_ones(lt) << (steps - lt);
+    return lp + popc32(hp & cols) - popc32(hn & cols);
+}
+
+template <int NP, class Txt>
+STRSIM_HD void jaro_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32_t lb, const uint32_t (&P)[NP], uint32_t &m_out,
+                        uint32_t &t_out)
+{
+    const uint32_t mx = la > lb ? la : lb;
+    const uint32_t half = mx >> 1;
+    const uint32_t bound = (half ? half : 1u) - 1u;
+    const uint32_t lbmask = low_ones(lb);
+    uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb), lomask = 0u, fb = 0u, fa = 0u;
+    for (uint32_t i = 0; i < steps; ++i) {
+        const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
+        const uint32_t Eq = eq_sym<NP>(P, lbmask, txt(i));
+        const uint32_t cand = bitop3<0x20>(Eq & himask, lomask | fb, live);
+        const uint32_t bit = cand & (0u - cand);
+        fb |= bit;
+        fa |= (bit ? 1u : 0u) << i;
+        himask = ((himask << 1) | 1u) & lbmask;
+        if (i >= bound) lomask = (lomask << 1) | 1u;
+    }
+    uint32_t t = 0u, rest = fb;
+    for (uint32_t i = 0; i < steps; ++i) {
+        const uint32_t on = 0u - ((fa >> i) & 1u);
+        const uint32_t jbit = rest & (0u - rest) & on;
+        rest ^= jbit;
+        const uint32_t Eq = eq_sym<NP>(P, lbmask, txt(i));
+        t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+    }
+    m_out = popc32(fb);
+    t_out = t;
+}
+
+template <int NP, class Txt>
+STRSIM_HD uint32_t isect_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32_t lb, const uint32_t (&P)[NP])
+{
+    const uint32_t lbmask = low_ones(lb);
+    uint32_t used = 0u;
+    for (uint32_t i = 0; i < steps; ++i) {
+        const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
+        const uint32_t cand = bitop3<0x20>(eq_sym<NP>(P, lbmask, txt(i)), used, live);
+        used |= cand & (0u - cand);
+    }
+    return popc32(used);
+}
+
+// One lane's result: text symbols txt(0 .. la), pattern symbols pat(0 .. lb), 1 <= la, lb <= 32.
+// For Jaro-Winkler the common prefix is counted on the symbols (strsim.rs:261-266).
+template <int MEASURE, int NP, class Txt, class Pat>
+STRSIM_HD double lane_sym_result(const Txt &txt, uint32_t la, uint32_t steps, const Pat &pat, uint32_t lb)
+{
+    uint32_t P[NP];
+    build_planes_sym<NP>(pat, P);
+    if (MEASURE == LEVENSHTEIN) {
+        const uint32_t s = 32u - lb;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) P[k] <<= s;
+        return epilogue_levenshtein(lev_sym<NP>(txt, la, steps, P, lb), la, lb);
+    } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        uint32_t m, t;
+        jaro_sym<NP>(txt, la, steps, lb, P, m, t);
+        const double j = epilogue_jaro(m, t, la, lb);
+        if (MEASURE == JARO) return j;
+        uint32_t p = 0;
+        const uint32_t lim = la < lb ? (la < 4u ? la : 4u) : (lb < 4u ? lb : 4u);
+        while (p < lim && txt(p) == pat(p)) ++p;
+        return epilogue_jaro_winkler(j, p);
+    } else {
+        const uint32_t isect = isect_sym<NP>(txt, la, steps, lb, P);
+        return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+    }
+}
+
+} // namespace strsim

@@ -5,6 +5,7 @@
 #include <cstring>
 #include "strsim_lane_core.h"
 #include "strsim_lane_wide.h"
+#include "strsim_lane_sym.h"
 
 using namespace strsim;
 
@@ -129,4 +130,47 @@ extern "C" double harness_lane_pair_wide(int measure, int W, const uint8_t *a, u
     if (W == 1) return run_wide_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill);
     if (W == 2) return run_wide_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill);
     return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+}
+
+// ---- symbol (non-ASCII) cores ----------------------------------------------------------------------
+struct SymArr { const uint16_t *s; uint32_t operator()(uint32_t k) const { return s[k]; } };
+struct EmitArr { uint16_t *s; void operator()(uint32_t k, uint32_t cp) const { if (k < 40) s[k] = (uint16_t)cp; } };
+
+template <int M, int NP>
+static double run_sym_np(const uint16_t *ta, uint32_t la, const uint16_t *pb, uint32_t lb)
+{
+    return lane_sym_result<M, NP>(SymArr{ta}, la, la, SymArr{pb}, lb);
+}
+
+// returns -1.0 when the pair is not eligible (more than 32 scalar values, or one outside the BMP, or an empty side)
+extern "C" double harness_lane_pair_sym(int measure, const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, int force_np)
+{
+    if (na > 128 || nb > 128 || na == 0 || nb == 0) return -1.0;
+    uint32_t wa[32], wb[32];
+    std::memset(wa, 0xAB, sizeof wa);
+    std::memset(wb, 0xCD, sizeof wb);
+    std::memcpy(wa, a, na);
+    std::memcpy(wb, b, nb);
+    uint16_t sa[40], sb[40];
+    std::memset(sa, 0x5A, sizeof sa);
+    std::memset(sb, 0x33, sizeof sb);
+    bool big = false;
+    uint32_t ov = 0, av = 0xFFFFFFFFu;
+    const uint32_t la = utf8_decode_lane<32>(wa, na, (na + 3) / 4, EmitArr{sa}, big, ov, av);
+    const uint32_t lb = utf8_decode_lane<32>(wb, nb, (nb + 3) / 4, EmitArr{sb}, big, ov, av);
+    if (big || la > 32 || lb > 32) return -1.0;
+    const int np = force_np ? force_np : planes_needed_sym((ov ^ av) & 0xFFFFu);
+#define SYM_DISPATCH(M)                                                       \
+    switch (np) {                                                             \
+    case 8: return run_sym_np<M, 8>(sa, la, sb, lb);                          \
+    case 11: return run_sym_np<M, 11>(sa, la, sb, lb);                        \
+    default: return run_sym_np<M, 16>(sa, la, sb, lb);                        \
+    }
+    switch (measure) {
+    case LEVENSHTEIN: SYM_DISPATCH(LEVENSHTEIN)
+    case JARO: SYM_DISPATCH(JARO)
+    case JARO_WINKLER: SYM_DISPATCH(JARO_WINKLER)
+    case JACCARD: SYM_DISPATCH(JACCARD)
+    default: SYM_DISPATCH(SORENSEN_DICE)
+    }
 }

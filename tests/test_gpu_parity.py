@@ -82,6 +82,30 @@ def test_lane_path_random(S, ctx, measure, alphabet, lo, hi):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("alphabet", ["абвгдежзийклмнопрстуфхцчшщыэюя ", "abcdeéèüñöçß-'", "日本語中文字漢한국어テキスト", "αβγ abc жзи 語"])
+def test_short_non_ascii_lane_path(S, ctx, measure, alphabet):
+    """<= 32 scalar values per string in any BMP script: decoded per lane (k_lane_utf8), not one wave per pair."""
+    A, B = gen.pairs(hash((measure, alphabet)) & 0xFFFF, 12000, alphabet, 0, 30)
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    leftovers = sum(1 for a, b in zip(A, B) if not a or not b or len(a) > 32 or len(b) > 32
+                    or len(a.encode()) > 128 or len(b.encode()) > 128)
+    assert ctx.last_wave_rows <= leftovers + 64
+
+
+@pytest.mark.parametrize("measure", ["levenshtein", "jaro_winkler"])
+def test_non_ascii_eligibility_edges(S, ctx, measure):
+    """exactly 32 / 33 scalar values, 4-byte (astral) values, 128 / 129 bytes: the lane path must hand over cleanly."""
+    cases = [("я" * 32, "я" * 31 + "ю"), ("я" * 33, "я" * 33), ("я" * 33, "ю"), ("語" * 32, "語" * 30 + "漢字"),
+             ("語" * 42, "語" * 43), ("語" * 43, "語" * 42 + "x"), ("a😀b", "a😀c"), ("😀" * 8, "😀" * 7 + "𝄞"),
+             ("é" * 64, "é" * 64), ("é" * 64 + "e", "é" * 64), ("naïve", "naive"), ("Ünïcödé", "Unicode"), ("ß", "ss")]
+    A = [c[0] for c in cases] * 40
+    B = [c[1] for c in cases] * 40
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 4), A, B, measure)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_embedded_nul_and_control_bytes(S, ctx, measure):
     """A Rust &str may hold any scalar value, U+0000 included."""
     A, B = gen.pairs(91, 8000, "ab\x00\x01\x7f ", 0, 32)

@@ -23,7 +23,7 @@ CSRC = os.path.join(ROOT, "polars-strsim_amd", "csrc")
 def harness():
     so = os.path.join(HDIR, "liblane_core_harness.so")
     srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h"),
-            os.path.join(CSRC, "strsim_lane_wide.h")]
+            os.path.join(CSRC, "strsim_lane_wide.h"), os.path.join(CSRC, "strsim_lane_sym.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
                                "-I", CSRC, "-o", so, srcs[0]])
@@ -32,6 +32,8 @@ def harness():
     L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_wide.restype = C.c_double
     L.harness_lane_pair_wide.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
+    L.harness_lane_pair_sym.restype = C.c_double
+    L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
     L.harness_check_planes.restype = C.c_int
     L.harness_check_planes.argtypes = [C.c_char_p]
     return L
@@ -141,3 +143,50 @@ def test_wide_cores_length_boundaries(harness, measure):
             b = bytes(rng.choice(b"abc") for _ in range(lb))
             got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, la, b, lb, 0, ord("c"))
             assert bits(got) == bits(O.pair(measure, a, b)), (W, a, b)
+
+
+SCRIPTS = {
+    "latin1": "abcdeéèüñöçß ",
+    "cyrillic": "абвгдежзийклмнопрстуфхцчшщыэюя ",
+    "greek+ascii": "αβγδεζηθικλμνξοπρστυφχψω abc-",
+    "cjk": "日本語中文字漢한국어テキスト",
+    "mixed": "aé日я-α𝄞",  # includes an astral scalar value: not eligible for the symbol path
+}
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("script", sorted(SCRIPTS))
+def test_symbol_cores_bit_exact(harness, measure, script):
+    """Per-lane UTF-8 decode + up-to-16-plane cores (strsim_lane_sym.h) vs the oracle on scalar values."""
+    rng = random.Random(len(script) * 7 + O.MEASURE_ID[measure])
+    alpha = SCRIPTS[script]
+    eligible = 0
+    for n in range(1500):
+        la = rng.randint(1, 34)
+        a = "".join(rng.choice(alpha) for _ in range(la))
+        r = rng.random()
+        if r < 0.1:
+            b = a
+        elif r < 0.6:
+            bl = list(a)
+            for _ in range(rng.randint(1, 3)):
+                op = rng.randint(0, 2)
+                if op == 0:
+                    bl.insert(rng.randint(0, len(bl)), rng.choice(alpha))
+                elif op == 1 and bl:
+                    del bl[rng.randrange(len(bl))]
+                elif bl:
+                    bl[rng.randrange(len(bl))] = rng.choice(alpha)
+            b = "".join(bl)
+        else:
+            b = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 34)))
+        ab, bb = a.encode(), b.encode()
+        ok = 0 < len(a) <= 32 and 0 < len(b) <= 32 and len(ab) <= 128 and len(bb) <= 128 and all(ord(c) <= 0xFFFF for c in a + b)
+        for force in (0, 16):
+            got = harness.harness_lane_pair_sym(O.MEASURE_ID[measure], ab, len(ab), bb, len(bb), force)
+            if not ok:
+                assert got == -1.0, (a, b)
+            else:
+                assert bits(got) == bits(O.pair(measure, a, b)), (measure, a, b, got)
+        eligible += ok
+    assert eligible > 300 or script == "mixed"
