@@ -490,6 +490,18 @@ struct LdsSymEmit {
     __device__ __forceinline__ void operator()(uint32_t k, uint32_t cp) const { if (k < 32u) col[k * 64u] = (uint16_t)cp; }
 };
 
+// load one string's window (4*NDW bytes) and decode it into the lane's LDS symbol column; returns its scalar-value count
+template <int NDW>
+__device__ __forceinline__ uint32_t decode_column(const uint8_t *__restrict__ vals, uint32_t off, uint32_t len8, uint32_t total,
+                                                  bool has, uint32_t maxlen, uint16_t *col, bool &big, uint32_t &ov, uint32_t &av)
+{
+    uint32_t w[NDW];
+#pragma unroll
+    for (int d = 0; d < NDW; ++d) w[d] = 0u;
+    if (has) load_window_any<NDW>(vals, (int64_t)off, total, w);
+    return utf8_decode_lane<NDW>(w, len8, (maxlen + 3u) >> 2, LdsSymEmit{col}, big, ov, av);
+}
+
 template <int MEASURE>
 __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__restrict__ offA,
                                                           const uint8_t *__restrict__ valA, uint64_t rowsA,
@@ -575,19 +587,13 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                 bool big = false;
                 uint32_t ov = 0u, av = 0xFFFFFFFFu;
                 uint32_t la, lb;
-                {
-                    uint32_t w[U8_DW];
-#pragma unroll
-                    for (int d = 0; d < U8_DW; ++d) w[d] = 0u;
-                    if (has) load_window_any<U8_DW>(valA, (int64_t)a0, totalA, w);
-                    la = utf8_decode_lane<U8_DW>(w, la8, (wave_max_u8(la8) + 3u) >> 2, LdsSymEmit{colA}, big, ov, av);
-                }
-                {
-                    uint32_t w[U8_DW];
-#pragma unroll
-                    for (int d = 0; d < U8_DW; ++d) w[d] = 0u;
-                    if (has) load_window_any<U8_DW>(valB, (int64_t)b0, totalB, w);
-                    lb = utf8_decode_lane<U8_DW>(w, lb8, (wave_max_u8(lb8) + 3u) >> 2, LdsSymEmit{colB}, big, ov, av);
+                const uint32_t maxa = wave_max_u8(la8), maxb = wave_max_u8(lb8);
+                if (maxa <= 64u && maxb <= 64u) { // the common case: 64-byte windows
+                    la = decode_column<U8_DW / 2>(valA, a0, la8, totalA, has, maxa, colA, big, ov, av);
+                    lb = decode_column<U8_DW / 2>(valB, b0, lb8, totalB, has, maxb, colB, big, ov, av);
+                } else {
+                    la = decode_column<U8_DW>(valA, a0, la8, totalA, has, maxa, colA, big, ov, av);
+                    lb = decode_column<U8_DW>(valB, b0, lb8, totalB, has, maxb, colB, big, ov, av);
                 }
                 const bool empty = has && (la8 == 0u || lb8 == 0u); // exactly one side empty (both-empty rows never get here)
                 const bool ok = has && !empty && !big && la <= 32u && lb <= 32u;

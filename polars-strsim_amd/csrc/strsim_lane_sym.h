@@ -100,18 +100,25 @@ STRSIM_HD uint32_t lev_sym(const Txt &txt, uint32_t lt, uint32_t steps, const ui
     const uint32_t s = 32u - lp;
     const uint32_t valid = 0xFFFFFFFFu << s;
     uint32_t Pv = valid, Mv = ~Pv, hp = 0u, hn = 0u;
-    for (uint32_t j = 0; j < steps; ++j) {
-        const uint32_t Eq = eq_sym<NP>(P, valid, txt(j));
-        const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq | Mv);
-        const uint32_t HP = bitop3<0xF1>(Mv, D0, Pv);
-        const uint32_t HN = Pv & D0;
-        hp = (hp << 1) | (HP >> 31);
-        hn = (hn << 1) | (HN >> 31);
-        const uint32_t X = (HP << 1) | 1u;
-        Pv = bitop3<0xF1>(HN << 1, D0, X);
-        Mv = D0 & X;
+    const uint32_t steps4 = (steps + 3u) & ~3u; // whole groups of four columns: four symbol reads in flight at a time
+    for (uint32_t j = 0; j < steps4; j += 4u) {
+        uint32_t sy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sy[q] = txt(j + (uint32_t)q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t Eq = eq_sym<NP>(P, valid, sy[q]);
+            const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq | Mv);
+            const uint32_t HP = bitop3<0xF1>(Mv, D0, Pv);
+            const uint32_t HN = Pv & D0;
+            hp = (hp << 1) | (HP >> 31);
+            hn = (hn << 1) | (HN >> 31);
+            const uint32_t X = (HP << 1) | 1u;
+            Pv = bitop3<0xF1>(HN << 1, D0, X);
+            Mv = D0 & X;
+        }
     }
-    const uint32_t cols = low_ones(lt) << (steps - lt);
+    const uint32_t cols = low_ones(lt) << (steps4 - lt);
     return lp + popc32(hp & cols) - popc32(hn & cols);
 }
 
@@ -124,23 +131,38 @@ STRSIM_HD void jaro_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32_t lb
     const uint32_t bound = (half ? half : 1u) - 1u;
     const uint32_t lbmask = low_ones(lb);
     uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb), lomask = 0u, fb = 0u, fa = 0u;
-    for (uint32_t i = 0; i < steps; ++i) {
-        const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
-        const uint32_t Eq = eq_sym<NP>(P, lbmask, txt(i));
-        const uint32_t cand = bitop3<0x20>(Eq & himask, lomask | fb, live);
-        const uint32_t bit = cand & (0u - cand);
-        fb |= bit;
-        fa |= (bit ? 1u : 0u) << i;
-        himask = ((himask << 1) | 1u) & lbmask;
-        if (i >= bound) lomask = (lomask << 1) | 1u;
+    const uint32_t steps4 = (steps + 3u) & ~3u; // steps <= 32, so steps4 <= 32 as well
+    for (uint32_t i0 = 0; i0 < steps4; i0 += 4u) {
+        uint32_t sy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sy[q] = txt(i0 + (uint32_t)q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + (uint32_t)q;
+            const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
+            const uint32_t Eq = eq_sym<NP>(P, lbmask, sy[q]);
+            const uint32_t cand = bitop3<0x20>(Eq & himask, lomask | fb, live);
+            const uint32_t bit = cand & (0u - cand);
+            fb |= bit;
+            fa |= (bit ? 1u : 0u) << i;
+            himask = ((himask << 1) | 1u) & lbmask;
+            if (i >= bound) lomask = (lomask << 1) | 1u;
+        }
     }
     uint32_t t = 0u, rest = fb;
-    for (uint32_t i = 0; i < steps; ++i) {
-        const uint32_t on = 0u - ((fa >> i) & 1u);
-        const uint32_t jbit = rest & (0u - rest) & on;
-        rest ^= jbit;
-        const uint32_t Eq = eq_sym<NP>(P, lbmask, txt(i));
-        t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+    for (uint32_t i0 = 0; i0 < steps4; i0 += 4u) {
+        uint32_t sy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sy[q] = txt(i0 + (uint32_t)q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + (uint32_t)q;
+            const uint32_t on = 0u - ((fa >> i) & 1u);
+            const uint32_t jbit = rest & (0u - rest) & on;
+            rest ^= jbit;
+            const uint32_t Eq = eq_sym<NP>(P, lbmask, sy[q]);
+            t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+        }
     }
     m_out = popc32(fb);
     t_out = t;
@@ -151,10 +173,17 @@ STRSIM_HD uint32_t isect_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32
 {
     const uint32_t lbmask = low_ones(lb);
     uint32_t used = 0u;
-    for (uint32_t i = 0; i < steps; ++i) {
-        const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
-        const uint32_t cand = bitop3<0x20>(eq_sym<NP>(P, lbmask, txt(i)), used, live);
-        used |= cand & (0u - cand);
+    const uint32_t steps4 = (steps + 3u) & ~3u;
+    for (uint32_t i0 = 0; i0 < steps4; i0 += 4u) {
+        uint32_t sy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sy[q] = txt(i0 + (uint32_t)q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t live = (i0 + (uint32_t)q) < la ? 0xFFFFFFFFu : 0u;
+            const uint32_t cand = bitop3<0x20>(eq_sym<NP>(P, lbmask, sy[q]), used, live);
+            used |= cand & (0u - cand);
+        }
     }
     return popc32(used);
 }
