@@ -8,7 +8,8 @@
  * polars_strsim/__init__.py:11-16), checks the version symbol and calls `_polars_plugin_<name>` with the
  * input Series exported over the Arrow C Data Interface.  Neither crate's source is vendored in the
  * reference tree: the layouts below are restated from the published 0.43.1 / 0.11.0 sources and are
- * "verify on first contact" (SURVEY.md 8b); tests/test_plugin_abi.py drives them with pyarrow as the host.
+ * "verify on first contact" (SURVEY.md 8b); tests/test_plugin_abi_gpu.py and tests/test_abi_symbols.py drive them with
+ * pyarrow as the host (strsim_amd/arrow_host.py).
  *
  * Ownership (polars-ffi `import_series` / `export_series`): the callee owns every input SeriesExport and
  * every ArrowArray in it -- it calls each array's release and then the SeriesExport's release, once.  On
@@ -96,6 +97,12 @@ POLARS_PLUGIN_DECLARE(jaro)
 POLARS_PLUGIN_DECLARE(jaro_winkler)
 POLARS_PLUGIN_DECLARE(jaccard)
 POLARS_PLUGIN_DECLARE(sorensen_dice)
+
+/* Test hook, not part of the Polars contract: the plugin's host-side packing of one Series (rows [r0, r1)) into
+ * caller buffers, without touching the GPU.  See csrc/polars_plugin.cpp. */
+POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0, uint64_t r1, uint32_t *off_out,
+                                               uint8_t *val_out, uint64_t val_cap, uint64_t *rows_out, uint64_t *bytes_out,
+                                               uint8_t *valid_out, unsigned threads);
 
 #ifdef __cplusplus
 }

@@ -679,6 +679,42 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_error.
         field_entry(input_fields, n_fields, return_value);                                                      \
     }
 
+// Test hook (no GPU needed): run the host-side packing of rows [r0, r1) of one Series with `threads` helper threads into
+// caller-provided buffers -- the exact describe / range_bytes / pack_range code the plugin entry points use.  Owns and
+// releases the input like a plugin call.  Returns 0, or -1 with the message in _polars_plugin_get_last_error_message().
+POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0, uint64_t r1, uint32_t *off_out,
+                                               uint8_t *val_out, uint64_t val_cap, uint64_t *rows_out, uint64_t *bytes_out,
+                                               uint8_t *valid_out, unsigned threads)
+{
+    InputGuard guard{series, 1};
+    try {
+        Column c;
+        describe(*series, c);
+        if (rows_out) *rows_out = c.rows;
+        if (r1 > c.rows) r1 = c.rows;
+        if (r0 > r1) r0 = r1;
+        const uint64_t rows = r1 - r0;
+        unsigned T = threads ? threads : 1;
+        if (T > rows) T = rows ? (unsigned)rows : 1;
+        std::vector<uint64_t> part(T + 1, 0);
+        auto lo = [&](unsigned t) { return r0 + rows * t / T; };
+        fork_join(T, [&](unsigned t) { part[t + 1] = range_bytes(c, lo(t), lo(t + 1)); });
+        for (unsigned t = 0; t < T; ++t) part[t + 1] += part[t];
+        if (bytes_out) *bytes_out = part[T];
+        if (part[T] + 16 > val_cap) fail("test buffer too small");
+        off_out[0] = 0;
+        fork_join(T, [&](unsigned t) { pack_range(c, lo(t), lo(t + 1), off_out + (lo(t) - r0), part[t], part[t + 1], val_out); });
+        if (valid_out)
+            for (uint64_t r = r0; r < r1; ++r) valid_out[r - r0] = row_valid(c, r) ? 1 : 0;
+        return 0;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
+}
+
 POLARS_PLUGIN_DEFINE(levenshtein, STRSIM_LEVENSHTEIN)
 POLARS_PLUGIN_DEFINE(jaro, STRSIM_JARO)
 POLARS_PLUGIN_DEFINE(jaro_winkler, STRSIM_JARO_WINKLER)
