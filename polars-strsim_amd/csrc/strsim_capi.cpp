@@ -68,6 +68,8 @@ struct strsim_ctx {
     LaunchArgs slot_args[RING] = {}; // what each pending call was launched with (for the long-string pass)
     int slot_measure[RING] = {};     // STRSIM_NUM_MEASURES = the fused all-measures call
     double *slot_outs[RING][5] = {};
+    uint32_t *lev_ws = nullptr;      // scratch of k_wave_pairs<LEVENSHTEIN>'s non-ASCII fallback
+    size_t lev_ws_cap = 0;
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
     int head = 0;
@@ -211,6 +213,7 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
     for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
     if (c->slowmask) (void)hipFree(c->slowmask);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
+    if (c->lev_ws) (void)hipFree(c->lev_ws);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -277,6 +280,13 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
     la.wave_grid = c->num_cu * 8;
+    la.wave_grid_lev = c->num_cu * 28; // 7 waves per SIMD by registers
+    la.lev_ws = nullptr;
+    if (measure == STRSIM_LEVENSHTEIN || all) {
+        rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, (size_t)la.wave_grid_lev * 3u * (WAVE_CAP + 64) * sizeof(uint32_t));
+        if (rc) return rc;
+        la.lev_ws = c->lev_ws;
+    }
     la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;
     if (c->timing) {
         for (int i = 0; i < 3; ++i)

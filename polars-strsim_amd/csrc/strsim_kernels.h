@@ -22,6 +22,8 @@ struct LaunchArgs {
     DevStatus *status;            // zeroed by the caller
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
+    int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
+    uint32_t *lev_ws;             // its global scratch: wave_grid_lev * 3 * (WAVE_CAP + 64) words
     hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)
 };
 

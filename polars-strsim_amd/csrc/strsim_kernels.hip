@@ -756,14 +756,13 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
     const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
     const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
-    uint32_t score = m;
     uint32_t hout = 0u; // bit 0: +1, bit 1: -1
     const uint32_t T0 = j0.m ? j0.n + ((j0.m + 31u) >> 5) - 1u : 0u;
     const uint32_t T1 = j1.m ? j1.n + ((j1.m + 31u) >> 5) - 1u : 0u;
     const uint32_t T = T0 > T1 ? T0 : T1;
     for (uint32_t t = 0; t < T; ++t) {
         uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (blk == 0u) hin = 1u; // row 0 of the DP: D[0][j] - D[0][j-1] = +1
+        if (blk == 0u) hin = 1u; // the row above block 0: +1 per column
         const uint32_t j = t - blk;
         if (mine && j < n) {
             const uint32_t c = txt[j];
@@ -779,12 +778,18 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
             Mh = (Mh << 1) | hinN;
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
-            if (blk == B - 1u) score += (hout & 1u) - (hout >> 1);
         }
     }
+    // No running score: every block stops updating after its last column, so once all are done the column-n vertical
+    // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
+    // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
+    int v = mine ? (int)popc32(Pv) - (int)popc32(Mv) : 0;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d); // sums within each 32-lane half
     const uint32_t B0 = (j0.m + 31u) >> 5, B1 = (j1.m + 31u) >> 5;
-    dist0 = B0 ? (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(B0 - 1u)) : 0u;
-    dist1 = B1 ? (uint32_t)__builtin_amdgcn_readlane((int)score, (int)(32u + B1 - 1u)) : 0u;
+    const int v0 = __builtin_amdgcn_readlane(v, 0), v1 = __builtin_amdgcn_readlane(v, 32);
+    dist0 = B0 ? (uint32_t)((int)(32u * B0 - j0.m + j0.n) + v0) : 0u;
+    dist1 = B1 ? (uint32_t)((int)(32u * B1 - j1.m + j1.n) + v1) : 0u;
 }
 
 // Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
@@ -947,11 +952,18 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                                                    const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                    double *__restrict__ out, uint64_t n,
                                                    const unsigned long long *__restrict__ slowmask,
-                                                   DevStatus *__restrict__ status)
+                                                   DevStatus *__restrict__ status, uint32_t *__restrict__ lev_ws)
 {
-    __shared__ uint32_t sA[WAVE_CAP];
-    __shared__ uint32_t sB[WAVE_CAP];
-    __shared__ uint32_t aux[WAVE_CAP + 64];
+    // Levenshtein: the ASCII rows (the common case) run in wave_lev_blocks2, which is latency-bound and only needs the
+    // two staged byte strings in LDS -- so the scalar-value scratch of the non-ASCII fallback lives in a global
+    // workspace (lev_ws, 3 * (WAVE_CAP + 64) words per wave) and LDS no longer caps the kernel at 10 waves per CU.
+    constexpr bool LEV = MEASURE == LEVENSHTEIN;
+    __shared__ uint32_t sA_l[LEV ? 1 : WAVE_CAP];
+    __shared__ uint32_t sB_l[LEV ? 1 : WAVE_CAP];
+    __shared__ uint32_t aux_l[LEV ? 1 : WAVE_CAP + 64];
+    uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * 3u * (WAVE_CAP + 64) : sA_l;
+    uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
+    uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
     __shared__ uint8_t s_txt8[MEASURE == LEVENSHTEIN ? 2 : 1][MEASURE == LEVENSHTEIN ? WAVE_CAP : 4];
     __shared__ uint8_t s_order[64];
     const uint32_t lane = lane_id();
@@ -1122,7 +1134,8 @@ static void launch_pair(const LaunchArgs &a)
     const uint64_t nchunks = (a.n + 63u) >> 6;
     const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
     const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
-    const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
+    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev : (uint64_t)a.wave_grid;
+    const uint64_t g2 = nchunks < wg ? nchunks : wg;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
@@ -1138,7 +1151,7 @@ static void launch_pair(const LaunchArgs &a)
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status);
+                       a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.lev_ws);
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
 }
 
@@ -1168,13 +1181,14 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
     const uint64_t nchunks = (a.n + 63u) >> 6;
     const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
     const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
-    const uint64_t g2 = nchunks < (uint64_t)a.wave_grid ? nchunks : (uint64_t)a.wave_grid;
+    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev : (uint64_t)a.wave_grid;
+    const uint64_t g2 = nchunks < wg ? nchunks : wg;
     hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask);
     hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask, a.status);
+                       a.valB, a.rowsB, out, a.n, a.slowmask, a.status, a.lev_ws);
 }
 
 // All five measures of one frame: one fused lane kernel (five outputs), then the slow-row kernels per measure,
