@@ -54,6 +54,7 @@ struct strsim_ctx {
     bool own_stream = false;
     int num_cu = 0;
     int lane_wg_per_cu = 5; // STRSIM_LANE_WG_PER_CU overrides (tuning knob)
+    int lev_waves_per_cu = 24; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;
     size_t slowmask_cap = 0; // entries
@@ -186,6 +187,10 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         const int v = atoi(env);
         if (v >= 1 && v <= 16) c->lane_wg_per_cu = v;
     }
+    if (const char *env = getenv("STRSIM_LEV_WAVES_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 256) c->lev_waves_per_cu = v;
+    }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -268,7 +273,8 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         if (rc) return rc;
     }
     const uint64_t nchunks = (n + 63) >> 6;
-    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long));
+    // mask + backup (five-measure call) + the work list of k_lane_utf8 (one u32 per chunk)
+    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long) + nchunks * sizeof(uint32_t));
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->status + slot, 0, sizeof(DevStatus), c->stream));
 
@@ -277,10 +283,11 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
     la.out = outs[0]; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
+    la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
     la.wave_grid = c->num_cu * 8;
-    la.wave_grid_lev = c->num_cu * 28; // 7 waves per SIMD by registers
+    la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // LEV_JOBS staged texts (6 KB of LDS) per wave
     la.lev_ws = nullptr;
     if (measure == STRSIM_LEVENSHTEIN || all) {
         rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, (size_t)la.wave_grid_lev * 3u * (WAVE_CAP + 64) * sizeof(uint32_t));

@@ -11,14 +11,21 @@ struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs
     unsigned int huge_rows; // rows longer than WAVE_CAP (left for the long-string pass)
     unsigned int max_len;   // longest such string, bytes
-    unsigned int pad[13];
+    unsigned int pad0;
+    // per measure (the fused five-measure call runs the slow-row kernels once per measure):
+    unsigned int list_count[5]; // k_lane_utf8: chunks of 64 rows that still hold unfinished rows ...
+    unsigned int list_rows[5];  // ... and how many rows that is
+    unsigned int next_entry[5]; // k_wave_pairs: work-list entries handed out beyond the first static round
+    unsigned int pad1[13];
 };
+static_assert(sizeof(DevStatus) == 128, "DevStatus is 128 bytes");
 
 struct LaunchArgs {
     const uint32_t *offA; const uint8_t *valA; uint64_t rowsA;
     const uint32_t *offB; const uint8_t *valB; uint64_t rowsB;
     double *out; uint64_t n;
     unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
+    uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
     DevStatus *status;            // zeroed by the caller
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels

@@ -508,7 +508,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                                                           const uint32_t *__restrict__ offB,
                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                           double *__restrict__ out, uint64_t n,
-                                                          unsigned long long *__restrict__ slowmask)
+                                                          unsigned long long *__restrict__ slowmask,
+                                                          uint32_t *__restrict__ worklist, DevStatus *__restrict__ status)
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
     __shared__ uint32_t s_cnt[8];
@@ -623,6 +624,22 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
         }
         __syncthreads();
       }
+      // This is the last per-lane kernel: the chunks that still hold rows go onto k_wave_pairs' work list
+      // (order irrelevant), with their count and their rows for its work distribution.
+      const unsigned long long fin = cw < nchunks ? *reinterpret_cast<const volatile unsigned long long *>(slowmask + cw) : 0ull;
+      const unsigned long long bal = __ballot(fin != 0ull);
+      if (bal != 0ull) {
+          uint32_t rows = (uint32_t)__popcll(fin);
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) rows += (uint32_t)__shfl_xor((int)rows, d);
+          uint32_t pos = 0u;
+          if (lane == 0u) {
+              pos = atomicAdd(&status->list_count[MEASURE], (unsigned int)__popcll(bal));
+              atomicAdd(&status->list_rows[MEASURE], rows);
+          }
+          pos = uniform(pos);
+          if (fin != 0ull) worklist[pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)cw;
+      }
     }
 }
 
@@ -722,31 +739,44 @@ __device__ __forceinline__ uint32_t wave_levenshtein(const uint32_t *sA, uint32_
 }
 
 // Levenshtein distance of ASCII strings, block-based bit-parallel DP (Myers 1999 / Hyyro 2003, the published
-// "advanced block" step), TWO pairs per wave: lanes 0-31 work on job 0, lanes 32-63 on job 1.  Within a job,
-// lane k owns rows 32k .. 32k+31 of the LONGER string (<= 32 blocks = 1024 bytes) as bit-planes in registers,
-// the SHORTER string (bytes in LDS) supplies the columns; block k works on column t-k at step t and hands its
+// "advanced block" step), up to LEV_JOBS pairs per wave, each in its own run of lanes (sum of runs <= 64).  Within
+// a job, lane k owns rows 32k .. 32k+31 of the SHORTER string (<= 32 blocks = 1024 bytes) as bit-planes in registers,
+// the LONGER string (bytes in LDS) supplies the columns -- that orientation needs the fewest lane-steps,
+// ceil(m/32) * (n + ceil(m/32) - 1); block k works on column t-k at step t and hands its
 // bottom-row delta (+1/0/-1) to block k+1 through a one-lane DPP shift.  The pattern is left-aligned to the
 // top of its last block (window that ENDS at the end of the string), so every hand-off and the score row are
-// bit 31.  max(n + B - 1) steps of ~45 VALU for 32*B*n cells per job.
+// bit 31.  max(n + B - 1) steps of ~31 VALU (five planes) for 32*B*n cells per job.
+__device__ __forceinline__ uint32_t bfe_u32(uint32_t w, uint32_t off, uint32_t width)
+{
+    return (uint32_t)__builtin_amdgcn_ubfe(w, off, width); // width 0 -> 0
+}
+
+#ifndef STRSIM_LEV_JOBS
+#define STRSIM_LEV_JOBS 5
+#endif
+constexpr int LEV_JOBS = STRSIM_LEV_JOBS; // pairs advanced together by one wave (each owns a run of lanes)
 struct BlockJob {
-    const uint8_t *valP; // column holding the longer string
+    const uint8_t *valP; // column holding the pattern (the SHORTER string of the pair)
     uint32_t p0, m, totalP; // its byte offset / length, and the column's total bytes
-    uint32_t n;          // length of the shorter string (staged in LDS)
+    uint32_t n;          // length of the text (the longer string, staged in LDS)
+    uint32_t seg;        // first lane of the job's run of ceil(m / 32) lanes
+    uint32_t la, lb;     // byte (= scalar value) counts of the row, for the epilogue
+    uint64_t row;
 };
 
 template <int NP>
-__device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const BlockJob &j1, const uint8_t *txt0,
-                                                 const uint8_t *txt1, uint32_t &dist0, uint32_t &dist1)
+__device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T,
+                                                const uint8_t (*txts)[WAVE_CAP], double *__restrict__ out)
 {
     const uint32_t lane = lane_id();
-    const bool hi = lane >= 32u;
-    const uint32_t blk = lane & 31u;
-    const uint8_t *valP = hi ? j1.valP : j0.valP;
-    const uint32_t p0 = hi ? j1.p0 : j0.p0, m = hi ? j1.m : j0.m, totalP = hi ? j1.totalP : j0.totalP;
-    const uint32_t n = hi ? j1.n : j0.n;
-    const uint8_t *txt = hi ? txt1 : txt0;
-    const uint32_t B = (m + 31u) >> 5; // 0 for an empty job
-    const bool mine = blk < B;
+    uint32_t jdx = 0;
+    for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= jobs[q].seg ? 1u : 0u;
+    const uint8_t *valP = jobs[jdx].valP;
+    const uint32_t p0 = jobs[jdx].p0, m = jobs[jdx].m, totalP = jobs[jdx].totalP, n = jobs[jdx].n;
+    const uint32_t blk = lane - jobs[jdx].seg;
+    const uint8_t *txt = txts[jdx];
+    const uint32_t B = (m + 31u) >> 5;
+    const bool mine = blk < B; // lanes past the last job's run fall into it with blk >= B
     uint32_t w[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) w[d] = 0u;
@@ -756,40 +786,54 @@ __device__ __forceinline__ void wave_lev_blocks2(const BlockJob &j0, const Block
     const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
     const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
-    uint32_t hout = 0u; // bit 0: +1, bit 1: -1
-    const uint32_t T0 = j0.m ? j0.n + ((j0.m + 31u) >> 5) - 1u : 0u;
-    const uint32_t T1 = j1.m ? j1.n + ((j1.m + 31u) >> 5) - 1u : 0u;
-    const uint32_t T = T0 > T1 ? T0 : T1;
+    // Hand-off word of a block: bit 0 = +1, bit 1 = -1 leaving its bottom row.  The LAST block of a job publishes 0
+    // (nobody below it), so the first block of the next job -- like lane 0, which the shift fills with 0 -- reads 0
+    // and adds its own constant +1 (the row above block 0 grows by one per column) through `first`.
+    const uint32_t first = blk == 0u ? 1u : 0u;
+    const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published +1 bit
+    const uint32_t pubn = blk + 1u == B ? 0u : 2u;  // mask of the published -1 bit
+    uint32_t hout = 0u;
+    uint32_t c = txt[(0u - blk) & (uint32_t)(WAVE_CAP - 1)]; // column byte of step 0, fetched one step ahead
     for (uint32_t t = 0; t < T; ++t) {
-        uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (blk == 0u) hin = 1u; // the row above block 0: +1 per column
+        const uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
         const uint32_t j = t - blk;
+        const uint32_t cnext = txt[(j + 1u) & (uint32_t)(WAVE_CAP - 1)];
         if (mine && j < n) {
-            const uint32_t c = txt[j];
             uint32_t Eq = eq_mask<NP>(P, valid, c, 0);
-            const uint32_t hinP = hin & 1u, hinN = hin >> 1;
+            const uint32_t hinP = (hin & 1u) | first, hinN = hin >> 1;
             const uint32_t Xv = Eq | Mv;
             Eq |= hinN;
             const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint32_t Ph = Mv | ~(Xh | Pv);
             uint32_t Mh = Pv & Xh;
-            hout = (Ph >> 31) | ((Mh >> 31) << 1);
+            hout = bfe_u32(Ph, 31u, pubw) | ((Mh >> 30) & pubn);
             Ph = (Ph << 1) | hinP;
             Mh = (Mh << 1) | hinN;
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
         }
+        c = cnext;
     }
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
-    int v = mine ? (int)popc32(Pv) - (int)popc32(Mv) : 0;
+    int pre = mine ? (int)popc32(Pv) - (int)popc32(Mv) : 0; // -> inclusive prefix sum over the lanes
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d); // sums within each 32-lane half
-    const uint32_t B0 = (j0.m + 31u) >> 5, B1 = (j1.m + 31u) >> 5;
-    const int v0 = __builtin_amdgcn_readlane(v, 0), v1 = __builtin_amdgcn_readlane(v, 32);
-    dist0 = B0 ? (uint32_t)((int)(32u * B0 - j0.m + j0.n) + v0) : 0u;
-    dist1 = B1 ? (uint32_t)((int)(32u * B1 - j1.m + j1.n) + v1) : 0u;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(pre, d);
+        if (lane >= (uint32_t)d) pre += up;
+    }
+    // lane q finishes job q
+    const uint32_t q = lane < njobs ? lane : 0u;
+    const uint32_t qseg = jobs[q].seg, qm = jobs[q].m, qn = jobs[q].n;
+    const uint32_t qB = (qm + 31u) >> 5;
+    const int hi_sum = __shfl(pre, (int)(qseg + qB - 1u));
+    const int lo_sum = __shfl(pre, (int)(qseg ? qseg - 1u : 0u));
+    if (lane < njobs) {
+        const int sum = hi_sum - (qseg ? lo_sum : 0);
+        const uint32_t dist = (uint32_t)((int)(32u * qB - qm + qn) + sum);
+        out[jobs[q].row] = epilogue_levenshtein(dist, jobs[q].la, jobs[q].lb);
+    }
 }
 
 // Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
@@ -952,6 +996,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                                                    const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                    double *__restrict__ out, uint64_t n,
                                                    const unsigned long long *__restrict__ slowmask,
+                                                   const uint32_t *__restrict__ worklist,
                                                    DevStatus *__restrict__ status, uint32_t *__restrict__ lev_ws)
 {
     // Levenshtein: the ASCII rows (the common case) run in wave_lev_blocks2, which is latency-bound and only needs the
@@ -964,55 +1009,57 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * 3u * (WAVE_CAP + 64) : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
-    __shared__ uint8_t s_txt8[MEASURE == LEVENSHTEIN ? 2 : 1][MEASURE == LEVENSHTEIN ? WAVE_CAP : 4];
+    __shared__ uint8_t s_txt8[LEV ? LEV_JOBS : 1][WAVE_CAP];
+    __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
     __shared__ uint8_t s_order[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
-    const uint64_t nchunks = (n + 63u) >> 6;
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
-    // Levenshtein on ASCII rows: two rows are collected and run together (one per half wave)
-    BlockJob job[2] = {{nullptr, 0, 0, 0, 0}, {nullptr, 0, 0, 0, 0}};
-    uint64_t job_row[2] = {0, 0};
-    uint32_t job_la[2] = {0, 0}, job_lb[2] = {0, 0};
-    uint32_t njobs = 0;
+    // Levenshtein on ASCII rows: rows are collected until their lane runs fill the wave, then run together
+    uint32_t njobs = 0, job_lanes = 0, job_T = 0;
     uint32_t job_or6 = 0u, job_and6 = 0x60u; // bits 5/6 over the bytes of the pending jobs
     auto flush_jobs = [&]() {
         if (MEASURE != LEVENSHTEIN || njobs == 0u) return;
-        if (njobs == 1u) job[1] = BlockJob{nullptr, 0, 0, 0, 0};
         __syncthreads();
-        uint32_t d0, d1;
-        // five planes when bits 5 and 6 are constant over every byte of both jobs (a-z), else all seven
+        // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
         if ((job_or6 ^ job_and6) & 0x60u)
-            wave_lev_blocks2<7>(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+            wave_lev_blocks<7>(s_job, njobs, job_T, s_txt8, out);
         else
-            wave_lev_blocks2<5>(job[0], job[1], s_txt8[0], s_txt8[MEASURE == LEVENSHTEIN ? 1 : 0], d0, d1);
+            wave_lev_blocks<5>(s_job, njobs, job_T, s_txt8, out);
         job_or6 = 0u; job_and6 = 0x60u;
-        if (lane == 0u) {
-            out[job_row[0]] = epilogue_levenshtein(d0, job_la[0], job_lb[0]);
-            if (njobs == 2u) out[job_row[1]] = epilogue_levenshtein(d1, job_la[1], job_lb[1]);
-        }
         __syncthreads();
-        njobs = 0u;
+        njobs = 0u; job_lanes = 0u; job_T = 0u;
     };
 
-    // Chunks are dealt round-robin over the waves (chunk = k * nwaves + wave) so that a column full of long rows
-    // spreads over the whole chip; each wave fetches the mask words of its next 64 chunks with one load
-    // (lane k holds chunk k's word) and visits the non-zero ones.
-    const uint64_t nwaves = gridDim.x;
-    for (uint64_t kbase = 0; kbase * nwaves < nchunks; kbase += 64u) {
-        const uint64_t cmine = (kbase + lane) * nwaves + blockIdx.x;
-        const unsigned long long mword = cmine < nchunks ? slowmask[cmine] : 0ull;
+    // Work distribution: k_lane_utf8 has compacted the chunks that still hold rows into `worklist` (C entries, R rows).
+    // A wave takes `grab` entries at a time -- its first grab is static (entry blockIdx * grab, no atomic, so a call
+    // with a handful of slow rows costs none), the following ones come from a counter.  One contended atomic costs
+    // ~12 ns, so their number is budgeted against the work: at most max(8192, R / 64) grabs, i.e. chunk-by-chunk
+    // balance (tail of one chunk) when the column is full of long rows, bigger grabs when the slow rows are sparse.
+    const uint32_t C = status->list_count[MEASURE], R = status->list_rows[MEASURE];
+    const uint32_t budget = (R >> 6) > 8192u ? (R >> 6) : 8192u;
+    const uint32_t grab = C / budget >= 64u ? 64u : (C / budget ? C / budget : 1u);
+    for (uint32_t round = 0;; ++round) {
+        uint32_t got = blockIdx.x * grab;
+        if (round != 0u) {
+            if (lane == 0u) got = atomicAdd(&status->next_entry[MEASURE], grab);
+            got = uniform(got) + gridDim.x * grab;
+        }
+        if (got >= C) break;
+        const bool have = lane < grab && got + lane < C;
+        const uint32_t entry = have ? worklist[got + lane] : 0u;
+        const unsigned long long mword = have ? slowmask[entry] : 0ull;
         unsigned long long pending = __ballot(mword != 0ull);
         while (pending != 0ull) {
             const uint32_t src = (uint32_t)__builtin_ctzll(pending);
             pending &= pending - 1ull;
-            const uint64_t chunk = (kbase + src) * nwaves + blockIdx.x;
+            const uint64_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)entry, (int)src);
             unsigned long long mask =
                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
-            // Levenshtein runs two rows at a time for max(steps) of the two: visit the chunk's rows in descending
-            // order of their step count (shorter length + blocks of the longer - 1) so that partners are alike
+            // Levenshtein runs several rows at a time for max(steps) of them: visit the chunk's rows in descending
+            // order of their step count (longer length + blocks of the shorter - 1) so that partners are alike
             uint32_t nvisit = (uint32_t)__popcll(mask);
             if (MEASURE == LEVENSHTEIN && nvisit > 2u) {
                 uint32_t key = 0u;
@@ -1022,7 +1069,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const uint64_t ra = bcastA ? 0 : rw, rb = bcastB ? 0 : rw;
                     const uint32_t x = offA[ra + 1] - offA[ra], y = offB[rb + 1] - offB[rb];
                     const uint32_t mx = x > y ? x : y, mn = x < y ? x : y;
-                    key = (mn != 0u && mx <= (uint32_t)WAVE_CAP) ? mn + ((mx + 31u) >> 5) : 0u;
+                    key = (mn != 0u && mx <= (uint32_t)WAVE_CAP) ? mx + ((mn + 31u) >> 5) : 0u;
                 }
                 uint32_t rank = 0u;
                 for (unsigned long long mm = mask; mm != 0ull; mm &= mm - 1ull) {
@@ -1055,20 +1102,23 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     continue;
                 }
                 if (MEASURE == LEVENSHTEIN && la8 != 0u && lb8 != 0u) {
-                    // longer string = DP rows (registers, read from global), shorter = columns (LDS bytes)
-                    const bool a_long = la8 >= lb8;
-                    const uint8_t *ps = a_long ? valB + b0 : valA + a0;
-                    const uint32_t ns = a_long ? lb8 : la8;
+                    // shorter string = DP rows (registers, read from global), longer = columns (LDS bytes)
+                    const bool a_short = la8 <= lb8;
+                    const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
+                    const uint32_t Bn = (ms + 31u) >> 5;
+                    if (njobs == (uint32_t)LEV_JOBS || job_lanes + Bn > 64u) flush_jobs();
                     uint32_t o6 = job_or6, n6 = job_and6;
-                    const bool asc_l = wave_ascii_stage(a_long ? valA + a0 : valB + b0, a_long ? la8 : lb8, nullptr, o6, n6);
-                    const bool asc_s = wave_ascii_stage(ps, ns, s_txt8[njobs & 1u], o6, n6);
-                    if (asc_l && asc_s) {
+                    const bool asc_s = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
+                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, s_txt8[njobs], o6, n6);
+                    if (asc_l) {
                         job_or6 = o6; job_and6 = n6;
-                        job[njobs] = a_long ? BlockJob{valA, a0, la8, totalA, ns} : BlockJob{valB, b0, lb8, totalB, ns};
-                        job_row[njobs] = row;
-                        job_la[njobs] = la8;
-                        job_lb[njobs] = lb8;
-                        if (++njobs == 2u) flush_jobs();
+                        if (lane == 0u)
+                            s_job[njobs] = a_short ? BlockJob{valA, a0, ms, totalA, nl, job_lanes, la8, lb8, row}
+                                                   : BlockJob{valB, b0, ms, totalB, nl, job_lanes, la8, lb8, row};
+                        ++njobs;
+                        job_lanes += Bn;
+                        const uint32_t Tj = nl + Bn - 1u;
+                        job_T = job_T > Tj ? job_T : Tj;
                         continue;
                     }
                 }
@@ -1148,10 +1198,10 @@ static void launch_pair(const LaunchArgs &a)
         hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
         hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.lev_ws);
+                       a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
 }
 
@@ -1186,9 +1236,9 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
     hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask);
     hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask);
+                       a.valB, a.rowsB, out, a.n, a.slowmask, a.worklist, a.status);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask, a.status, a.lev_ws);
+                       a.valB, a.rowsB, out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
 }
 
 // All five measures of one frame: one fused lane kernel (five outputs), then the slow-row kernels per measure,
