@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
     __shared__ uint8_t s_txt8[LEV ? LEV_JOBS : 1][WAVE_CAP];
     __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
-    __shared__ uint8_t s_order[64];
+    __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
@@ -1055,21 +1055,27 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
             const uint32_t src = (uint32_t)__builtin_ctzll(pending);
             pending &= pending - 1ull;
             const uint64_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)entry, (int)src);
-            unsigned long long mask =
+            const unsigned long long mask =
                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
-            // Levenshtein runs several rows at a time for max(steps) of them: visit the chunk's rows in descending
-            // order of their step count (longer length + blocks of the shorter - 1) so that partners are alike
-            uint32_t nvisit = (uint32_t)__popcll(mask);
-            if (MEASURE == LEVENSHTEIN && nvisit > 2u) {
-                uint32_t key = 0u;
+            // Levenshtein runs several rows at a time for max(steps) of them: the chunk's rows are ranked in
+            // descending order of their step count (longer length + blocks of the shorter - 1) so that the rows of
+            // a batch are alike, and each batch is filled first-fit from that order (rows whose lane run does not
+            // fit any more are skipped and start or join a later batch).
+            const uint32_t nvisit = (uint32_t)__popcll(mask);
+            unsigned long long todo = mask; // bit = row of the chunk; Levenshtein: bit = position in the ranking
+            if (MEASURE == LEVENSHTEIN) {
+                uint32_t key = 0u, nblk = 0u;
                 const bool mine = (mask >> lane) & 1ull;
                 if (mine) {
                     const uint64_t rw = chunk * 64u + lane;
                     const uint64_t ra = bcastA ? 0 : rw, rb = bcastB ? 0 : rw;
                     const uint32_t x = offA[ra + 1] - offA[ra], y = offB[rb + 1] - offB[rb];
                     const uint32_t mx = x > y ? x : y, mn = x < y ? x : y;
-                    key = (mn != 0u && mx <= (uint32_t)WAVE_CAP) ? mx + ((mn + 31u) >> 5) : 0u;
+                    if (mn != 0u && mx <= (uint32_t)WAVE_CAP) {
+                        nblk = (mn + 31u) >> 5;
+                        key = mx + nblk;
+                    }
                 }
                 uint32_t rank = 0u;
                 for (unsigned long long mm = mask; mm != 0ull; mm &= mm - 1ull) {
@@ -1078,17 +1084,24 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     rank += (kj > key || (kj == key && jl < lane)) ? 1u : 0u;
                 }
                 __syncthreads();
-                if (mine) s_order[rank] = (uint8_t)lane;
-                __syncthreads();
-            }
-            for (uint32_t vi = 0; vi < nvisit; ++vi) {
-                uint32_t bitpos;
-                if (MEASURE == LEVENSHTEIN && nvisit > 2u) {
-                    bitpos = uniform((uint32_t)s_order[vi]);
-                } else {
-                    bitpos = (uint32_t)__builtin_ctzll(mask);
-                    mask &= mask - 1ull;
+                if (mine) {
+                    s_order[rank] = (uint8_t)lane;
+                    s_blk[rank] = (uint8_t)nblk; // 0: not a candidate for the block kernel (empty side / too long)
                 }
+                __syncthreads();
+                todo = nvisit == 64u ? ~0ull : ((1ull << nvisit) - 1ull);
+            }
+            while (todo != 0ull) {
+              bool full = false;
+              for (unsigned long long scan = todo; scan != 0ull && !full; scan &= scan - 1ull) {
+                const uint32_t vi = (uint32_t)__builtin_ctzll(scan);
+                uint32_t bitpos = vi;
+                if (MEASURE == LEVENSHTEIN) {
+                    const uint32_t need = uniform((uint32_t)s_blk[vi]);
+                    if (job_lanes + need > 64u) continue; // no room in this batch
+                    bitpos = uniform((uint32_t)s_order[vi]);
+                }
+                todo &= ~(1ull << vi);
                 const uint64_t row = chunk * 64u + bitpos;
                 const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
                 const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
@@ -1106,7 +1119,6 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const bool a_short = la8 <= lb8;
                     const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
                     const uint32_t Bn = (ms + 31u) >> 5;
-                    if (njobs == (uint32_t)LEV_JOBS || job_lanes + Bn > 64u) flush_jobs();
                     uint32_t o6 = job_or6, n6 = job_and6;
                     const bool asc_s = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
                     const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, s_txt8[njobs], o6, n6);
@@ -1119,11 +1131,14 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                         job_lanes += Bn;
                         const uint32_t Tj = nl + Bn - 1u;
                         job_T = job_T > Tj ? job_T : Tj;
+                        full = njobs == (uint32_t)LEV_JOBS || job_lanes == 64u;
                         continue;
                     }
                 }
                 const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP);
                 if (lane == 0u) out[row] = r;
+              }
+              if (full || todo != 0ull) flush_jobs(); // rows are left that did not fit: run what has been collected
             }
         }
     }
