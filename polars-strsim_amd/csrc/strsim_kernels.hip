@@ -754,7 +754,8 @@ __device__ __forceinline__ uint32_t bfe_u32(uint32_t w, uint32_t off, uint32_t w
 #ifndef STRSIM_LEV_JOBS
 #define STRSIM_LEV_JOBS 5
 #endif
-constexpr int LEV_JOBS = STRSIM_LEV_JOBS; // pairs advanced together by one wave (each owns a run of lanes)
+constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
+constexpr int TXT_PAD = 64; // bytes in front of and behind a staged text (see wave_lev_blocks) // pairs advanced together by one wave (each owns a run of lanes)
 struct BlockJob {
     const uint8_t *valP; // column holding the pattern (the SHORTER string of the pair)
     uint32_t p0, m, totalP; // its byte offset / length, and the column's total bytes
@@ -766,7 +767,7 @@ struct BlockJob {
 
 template <int NP>
 __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T,
-                                                const uint8_t (*txts)[WAVE_CAP], double *__restrict__ out)
+                                                const uint8_t (*txts)[WAVE_CAP + 2 * TXT_PAD], double *__restrict__ out)
 {
     const uint32_t lane = lane_id();
     uint32_t jdx = 0;
@@ -793,27 +794,37 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published +1 bit
     const uint32_t pubn = blk + 1u == B ? 0u : 2u;  // mask of the published -1 bit
     uint32_t hout = 0u;
-    uint32_t c = txt[(0u - blk) & (uint32_t)(WAVE_CAP - 1)]; // column byte of step 0, fetched one step ahead
-    for (uint32_t t = 0; t < T; ++t) {
+    // Column t - blk of the text at step t.  The staged texts have TXT_PAD bytes in front and behind (never used as
+    // columns: a block is idle for blk steps before and at most 32 steps after its own columns), so the byte for the
+    // NEXT step is fetched unconditionally, one step ahead, by a pointer that just moves on.
+    const uint8_t *const col0 = txt + TXT_PAD;
+    const uint32_t ncol = mine ? n : 0u;
+    int32_t j = -(int32_t)blk;
+    auto step = [&](uint32_t c) {
         const uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-        const uint32_t j = t - blk;
-        const uint32_t cnext = txt[(j + 1u) & (uint32_t)(WAVE_CAP - 1)];
-        if (mine && j < n) {
-            uint32_t Eq = eq_mask<NP>(P, valid, c, 0);
+        if ((uint32_t)j < ncol) {
+            const uint32_t Eq0 = eq_mask<NP>(P, valid, c, 0);
             const uint32_t hinP = (hin & 1u) | first, hinN = hin >> 1;
-            const uint32_t Xv = Eq | Mv;
-            Eq |= hinN;
-            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            uint32_t Ph = Mv | ~(Xh | Pv);
-            uint32_t Mh = Pv & Xh;
+            const uint32_t Xv = Eq0 | Mv;
+            const uint32_t Eq = Eq0 | hinN;
+            const uint32_t Xh = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq); // (sum ^ Pv) | Eq
+            const uint32_t Ph = bitop3<0xF1>(Mv, Xh, Pv);             // Mv | ~(Xh | Pv)
+            const uint32_t Mh = Pv & Xh;
             hout = bfe_u32(Ph, 31u, pubw) | ((Mh >> 30) & pubn);
-            Ph = (Ph << 1) | hinP;
-            Mh = (Mh << 1) | hinN;
-            Pv = Mh | ~(Xv | Ph);
-            Mv = Ph & Xv;
+            const uint32_t PhS = (Ph << 1) | hinP, MhS = (Mh << 1) | hinN;
+            Pv = bitop3<0xF1>(MhS, Xv, PhS);                          // MhS | ~(Xv | PhS)
+            Mv = PhS & Xv;
         }
-        c = cnext;
+        ++j;
+    };
+    uint32_t c0 = col0[j], t = 0;
+    for (; t + 2u <= T; t += 2u) { // two steps per trip: the fetched bytes alternate between two registers
+        const uint32_t c1 = col0[j + 1];
+        step(c0);
+        c0 = col0[j + 1];
+        step(c1);
     }
+    if (t < T) step(c0);
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * 3u * (WAVE_CAP + 64) : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
-    __shared__ uint8_t s_txt8[LEV ? LEV_JOBS : 1][WAVE_CAP];
+    __shared__ uint8_t s_txt8[LEV ? LEV_JOBS : 1][LEV ? WAVE_CAP + 2 * TXT_PAD : 4];
     __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
     __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
@@ -1020,16 +1031,18 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t njobs = 0, job_lanes = 0, job_T = 0;
     uint32_t job_or6 = 0u, job_and6 = 0x60u; // bits 5/6 over the bytes of the pending jobs
     auto flush_jobs = [&]() {
-        if (MEASURE != LEVENSHTEIN || njobs == 0u) return;
-        __syncthreads();
-        // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
-        if ((job_or6 ^ job_and6) & 0x60u)
-            wave_lev_blocks<7>(s_job, njobs, job_T, s_txt8, out);
-        else
-            wave_lev_blocks<5>(s_job, njobs, job_T, s_txt8, out);
-        job_or6 = 0u; job_and6 = 0x60u;
-        __syncthreads();
-        njobs = 0u; job_lanes = 0u; job_T = 0u;
+        if constexpr (LEV) {
+            if (njobs == 0u) return;
+            __syncthreads();
+            // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
+            if ((job_or6 ^ job_and6) & 0x60u)
+                wave_lev_blocks<7>(s_job, njobs, job_T, s_txt8, out);
+            else
+                wave_lev_blocks<5>(s_job, njobs, job_T, s_txt8, out);
+            job_or6 = 0u; job_and6 = 0x60u;
+            __syncthreads();
+            njobs = 0u; job_lanes = 0u; job_T = 0u;
+        }
     };
 
     // Work distribution: k_lane_utf8 has compacted the chunks that still hold rows into `worklist` (C entries, R rows).
@@ -1121,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const uint32_t Bn = (ms + 31u) >> 5;
                     uint32_t o6 = job_or6, n6 = job_and6;
                     const bool asc_s = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
-                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, s_txt8[njobs], o6, n6);
+                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, s_txt8[njobs] + TXT_PAD, o6, n6);
                     if (asc_l) {
                         job_or6 = o6; job_and6 = n6;
                         if (lane == 0u)
