@@ -54,7 +54,7 @@ struct strsim_ctx {
     bool own_stream = false;
     int num_cu = 0;
     int lane_wg_per_cu = 5; // STRSIM_LANE_WG_PER_CU overrides (tuning knob)
-    int lev_waves_per_cu = 24; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
+    int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;
     size_t slowmask_cap = 0; // entries
@@ -69,7 +69,7 @@ struct strsim_ctx {
     LaunchArgs slot_args[RING] = {}; // what each pending call was launched with (for the long-string pass)
     int slot_measure[RING] = {};     // STRSIM_NUM_MEASURES = the fused all-measures call
     double *slot_outs[RING][5] = {};
-    uint32_t *lev_ws = nullptr;      // scratch of k_wave_pairs<LEVENSHTEIN>'s non-ASCII fallback
+    uint32_t *lev_ws = nullptr;      // scratch of k_wave_pairs<LEVENSHTEIN>: staged texts + non-ASCII fallback arrays
     size_t lev_ws_cap = 0;
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
@@ -287,10 +287,10 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
     la.wave_grid = c->num_cu * 8;
-    la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // LEV_JOBS staged texts (6 KB of LDS) per wave
+    la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // 8 KB of LDS (match table) per wave
     la.lev_ws = nullptr;
     if (measure == STRSIM_LEVENSHTEIN || all) {
-        rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, (size_t)la.wave_grid_lev * 3u * (WAVE_CAP + 64) * sizeof(uint32_t));
+        rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, (size_t)la.wave_grid_lev * LEV_WS_WORDS * sizeof(uint32_t));
         if (rc) return rc;
         la.lev_ws = c->lev_ws;
     }

@@ -7,6 +7,16 @@ namespace strsim {
 
 constexpr int WAVE_CAP = 1024; // wave-per-pair kernels: max bytes (hence scalar values) per string
 
+// k_wave_pairs<LEVENSHTEIN>: pairs advanced together by one wave, and the per-wave global scratch it needs:
+// the three scalar-value arrays of the non-ASCII fallback, then LEV_JOBS staged texts with TXT_PAD bytes around each.
+#ifndef STRSIM_LEV_JOBS
+#define STRSIM_LEV_JOBS 5
+#endif
+constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
+constexpr int TXT_PAD = 64;
+constexpr int TXT_SLOT = WAVE_CAP + 2 * TXT_PAD;
+constexpr int LEV_WS_WORDS = 3 * (WAVE_CAP + 64) + LEV_JOBS * TXT_SLOT / 4; // per wave
+
 struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs
     unsigned int huge_rows; // rows longer than WAVE_CAP (left for the long-string pass)
@@ -30,7 +40,7 @@ struct LaunchArgs {
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
-    uint32_t *lev_ws;             // its global scratch: wave_grid_lev * 3 * (WAVE_CAP + 64) words
+    uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words
     hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)
 };
 

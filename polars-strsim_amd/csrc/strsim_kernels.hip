@@ -751,11 +751,6 @@ __device__ __forceinline__ uint32_t bfe_u32(uint32_t w, uint32_t off, uint32_t w
     return (uint32_t)__builtin_amdgcn_ubfe(w, off, width); // width 0 -> 0
 }
 
-#ifndef STRSIM_LEV_JOBS
-#define STRSIM_LEV_JOBS 5
-#endif
-constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
-constexpr int TXT_PAD = 64; // bytes in front of and behind a staged text (see wave_lev_blocks) // pairs advanced together by one wave (each owns a run of lanes)
 struct BlockJob {
     const uint8_t *valP; // column holding the pattern (the SHORTER string of the pair)
     uint32_t p0, m, totalP; // its byte offset / length, and the column's total bytes
@@ -765,17 +760,21 @@ struct BlockJob {
     uint64_t row;
 };
 
-template <int NP>
+// TAB (five planes only): the match masks of the 32 possible codes are tabulated per lane in LDS (tab[code][lane],
+// 8 KB per wave) when the batch starts, and a step reads its mask -- fetched one step ahead, the column byte two
+// steps ahead -- instead of computing it: 22 instead of 31 VALU per step.
+template <int NP, bool TAB>
 __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T,
-                                                const uint8_t (*txts)[WAVE_CAP + 2 * TXT_PAD], double *__restrict__ out)
+                                                const uint8_t *txts, uint32_t *tab, double *__restrict__ out)
 {
+    static_assert(!TAB || NP == 5, "the LDS table holds 32 codes");
     const uint32_t lane = lane_id();
     uint32_t jdx = 0;
     for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= jobs[q].seg ? 1u : 0u;
     const uint8_t *valP = jobs[jdx].valP;
     const uint32_t p0 = jobs[jdx].p0, m = jobs[jdx].m, totalP = jobs[jdx].totalP, n = jobs[jdx].n;
     const uint32_t blk = lane - jobs[jdx].seg;
-    const uint8_t *txt = txts[jdx];
+    const uint8_t *txt = txts + jdx * TXT_SLOT; // global scratch, staged by this wave
     const uint32_t B = (m + 31u) >> 5;
     const bool mine = blk < B; // lanes past the last job's run fall into it with blk >= B
     uint32_t w[8];
@@ -794,16 +793,17 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published +1 bit
     const uint32_t pubn = blk + 1u == B ? 0u : 2u;  // mask of the published -1 bit
     uint32_t hout = 0u;
-    // Column t - blk of the text at step t.  The staged texts have TXT_PAD bytes in front and behind (never used as
-    // columns: a block is idle for blk steps before and at most 32 steps after its own columns), so the byte for the
-    // NEXT step is fetched unconditionally, one step ahead, by a pointer that just moves on.
+    // Column j = t - blk of the text at step t.  The staged texts have TXT_PAD bytes in front and behind (never used
+    // as columns: a block is idle for blk steps before and at most 32 steps after its own columns), so a lane just
+    // walks on: one (unaligned) dword = four columns per four steps, fetched two dwords ahead.
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const uint8_t *const col0 = txt + TXT_PAD;
     const uint32_t ncol = mine ? n : 0u;
     int32_t j = -(int32_t)blk;
-    auto step = [&](uint32_t c) {
+    auto fetch = [&](int32_t at) { return *reinterpret_cast<const u32_unaligned *>(col0 + at); };
+    auto step = [&](uint32_t Eq0) {
         const uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
         if ((uint32_t)j < ncol) {
-            const uint32_t Eq0 = eq_mask<NP>(P, valid, c, 0);
             const uint32_t hinP = (hin & 1u) | first, hinN = hin >> 1;
             const uint32_t Xv = Eq0 | Mv;
             const uint32_t Eq = Eq0 | hinN;
@@ -817,14 +817,31 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
         }
         ++j;
     };
-    uint32_t c0 = col0[j], t = 0;
-    for (; t + 2u <= T; t += 2u) { // two steps per trip: the fetched bytes alternate between two registers
-        const uint32_t c1 = col0[j + 1];
-        step(c0);
-        c0 = col0[j + 1];
-        step(c1);
+    uint32_t w0 = fetch(j), w1 = fetch(j + 4);
+    uint32_t t = 0;
+    if (TAB) {
+        uint32_t *const trow = tab + lane; // this lane's column of the table: written and read by this lane only
+#pragma unroll
+        for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<NP>(P, valid, (uint32_t)code, 0);
+        for (; t + 4u <= T; t += 4u) {
+            const uint32_t w2 = fetch(j + 8);
+            uint32_t e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(w0, 8u * q, 5u) * 64u];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) step(e[q]);
+            w0 = w1; w1 = w2;
+        }
+        for (uint32_t q = 0; t < T; ++t, ++q) step(trow[bfe_u32(w0, 8u * q, 5u) * 64u]);
+    } else {
+        for (; t + 4u <= T; t += 4u) {
+            const uint32_t w2 = fetch(j + 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) step(eq_mask<NP>(P, valid, w0, q));
+            w0 = w1; w1 = w2;
+        }
+        for (uint32_t q = 0; t < T; ++t, ++q) step(eq_mask<NP>(P, valid, w0 >> (8u * q), 0));
     }
-    if (t < T) step(c0);
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
@@ -1017,11 +1034,12 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     __shared__ uint32_t sA_l[LEV ? 1 : WAVE_CAP];
     __shared__ uint32_t sB_l[LEV ? 1 : WAVE_CAP];
     __shared__ uint32_t aux_l[LEV ? 1 : WAVE_CAP + 64];
-    uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * 3u * (WAVE_CAP + 64) : sA_l;
+    uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * LEV_WS_WORDS : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
-    __shared__ uint8_t s_txt8[LEV ? LEV_JOBS : 1][LEV ? WAVE_CAP + 2 * TXT_PAD : 4];
+    uint8_t *const g_txt = reinterpret_cast<uint8_t *>(aux + (WAVE_CAP + 64)); // LEV: LEV_JOBS staged texts (global)
     __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
+    __shared__ uint32_t s_tab[LEV ? 32 * 64 : 1]; // wave_lev_blocks<5, true>: match masks by code and lane
     __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
@@ -1033,12 +1051,14 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     auto flush_jobs = [&]() {
         if constexpr (LEV) {
             if (njobs == 0u) return;
+            // the staged texts were written by this wave's own lanes (plain global stores): the workgroup-scope
+            // fence of the barrier orders them before the loads below, and the CU's L1 is coherent for its own waves
             __syncthreads();
             // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
             if ((job_or6 ^ job_and6) & 0x60u)
-                wave_lev_blocks<7>(s_job, njobs, job_T, s_txt8, out);
+                wave_lev_blocks<7, false>(s_job, njobs, job_T, g_txt, s_tab, out);
             else
-                wave_lev_blocks<5>(s_job, njobs, job_T, s_txt8, out);
+                wave_lev_blocks<5, true>(s_job, njobs, job_T, g_txt, s_tab, out);
             job_or6 = 0u; job_and6 = 0x60u;
             __syncthreads();
             njobs = 0u; job_lanes = 0u; job_T = 0u;
@@ -1134,7 +1154,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const uint32_t Bn = (ms + 31u) >> 5;
                     uint32_t o6 = job_or6, n6 = job_and6;
                     const bool asc_s = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
-                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, s_txt8[njobs] + TXT_PAD, o6, n6);
+                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, g_txt + njobs * TXT_SLOT + TXT_PAD, o6, n6);
                     if (asc_l) {
                         job_or6 = o6; job_and6 = n6;
                         if (lane == 0u)

@@ -147,6 +147,21 @@ def test_long_ascii_levenshtein_blocks(S, ctx, alphabet):
     assert_bit_exact(got, O.batch_strings("levenshtein", A, B, 8), A, B, "levenshtein")
 
 
+def test_long_ascii_levenshtein_many_batches_per_wave(S, monkeypatch):
+    """Few resident waves (one per CU), so every wave runs many batches and takes several chunks from the work list:
+    the staged-text slots (global scratch) and the LDS match table are reused over and over."""
+    monkeypatch.setenv("STRSIM_LEV_WAVES_PER_CU", "1")
+    c = S.Context(0)
+    try:
+        A, B = gen.pairs(77, 24000, gen.ASCII_LOWER, 100, 1024, max_bytes=1024)
+        A2, B2 = gen.pairs(78, 6000, gen.ASCII_LOWER + gen.ASCII_LOWER.upper() + " .,", 100, 1024, max_bytes=1024)
+        A, B = A + A2, B + B2
+        got = gpu(S, c, "levenshtein", A, B)
+        assert_bit_exact(got, O.batch_strings("levenshtein", A, B, 16), A, B, "levenshtein")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
