@@ -760,14 +760,15 @@ struct BlockJob {
     uint64_t row;
 };
 
-// TAB (five planes only): the match masks of the 32 possible codes are tabulated per lane in LDS (tab[code][lane],
-// 8 KB per wave) when the batch starts, and a step reads its mask -- fetched one step ahead, the column byte two
-// steps ahead -- instead of computing it: 22 instead of 31 VALU per step.
-template <int NP, bool TAB>
+// Match masks: the masks of the 32 possible values of the low five bits of a byte are tabulated per lane in LDS when
+// the batch starts (tab[code][lane], 8 KB per wave, each lane writes and reads its own column only), and a step
+// reads its mask instead of computing it; bits 5 and 6 are compared with two bit-planes on top of that (NP == 7)
+// unless they are the same in every byte of the batch (NP == 5; a-z, A-Z, digits ...): 22 / 26 VALU per step.
+template <int NP>
 __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T,
                                                 const uint8_t *txts, uint32_t *tab, double *__restrict__ out)
 {
-    static_assert(!TAB || NP == 5, "the LDS table holds 32 codes");
+    static_assert(NP == 5 || NP == 7, "five tabulated planes, plus two computed ones for general ASCII");
     const uint32_t lane = lane_id();
     uint32_t jdx = 0;
     for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= jobs[q].seg ? 1u : 0u;
@@ -819,29 +820,32 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     };
     uint32_t w0 = fetch(j), w1 = fetch(j + 4);
     uint32_t t = 0;
-    if (TAB) {
-        uint32_t *const trow = tab + lane; // this lane's column of the table: written and read by this lane only
+    uint32_t *const trow = tab + lane;
+    {
+        uint32_t P5[5];
 #pragma unroll
-        for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<NP>(P, valid, (uint32_t)code, 0);
-        for (; t + 4u <= T; t += 4u) {
-            const uint32_t w2 = fetch(j + 8);
-            uint32_t e[4];
+        for (int k = 0; k < 5; ++k) P5[k] = P[k];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(w0, 8u * q, 5u) * 64u];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) step(e[q]);
-            w0 = w1; w1 = w2;
-        }
-        for (uint32_t q = 0; t < T; ++t, ++q) step(trow[bfe_u32(w0, 8u * q, 5u) * 64u]);
-    } else {
-        for (; t + 4u <= T; t += 4u) {
-            const uint32_t w2 = fetch(j + 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) step(eq_mask<NP>(P, valid, w0, q));
-            w0 = w1; w1 = w2;
-        }
-        for (uint32_t q = 0; t < T; ++t, ++q) step(eq_mask<NP>(P, valid, w0 >> (8u * q), 0));
+        for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<5>(P5, valid, (uint32_t)code, 0);
     }
+    // mask of the byte `q` of w: table look-up, then the two high planes
+    auto high_planes = [&](uint32_t e, uint32_t w, int q) {
+        if (NP == 7) {
+            e = bitop3<0x90>(e, P[NP - 2], bit_fill(w, 8 * q + 5));
+            e = bitop3<0x90>(e, P[NP - 1], bit_fill(w, 8 * q + 6));
+        }
+        return e;
+    };
+    for (; t + 4u <= T; t += 4u) {
+        const uint32_t w2 = fetch(j + 8);
+        uint32_t e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(w0, 8u * q, 5u) * 64u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) step(high_planes(e[q], w0, q));
+        w0 = w1; w1 = w2;
+    }
+    for (; t < T; ++t, w0 >>= 8) step(high_planes(trow[(w0 & 31u) * 64u], w0, 0));
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
     uint8_t *const g_txt = reinterpret_cast<uint8_t *>(aux + (WAVE_CAP + 64)); // LEV: LEV_JOBS staged texts (global)
     __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
-    __shared__ uint32_t s_tab[LEV ? 32 * 64 : 1]; // wave_lev_blocks<5, true>: match masks by code and lane
+    __shared__ uint32_t s_tab[LEV ? 32 * 64 : 1]; // wave_lev_blocks: match masks by code (low five bits) and lane
     __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
@@ -1056,9 +1060,9 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
             __syncthreads();
             // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
             if ((job_or6 ^ job_and6) & 0x60u)
-                wave_lev_blocks<7, false>(s_job, njobs, job_T, g_txt, s_tab, out);
+                wave_lev_blocks<7>(s_job, njobs, job_T, g_txt, s_tab, out);
             else
-                wave_lev_blocks<5, true>(s_job, njobs, job_T, g_txt, s_tab, out);
+                wave_lev_blocks<5>(s_job, njobs, job_T, g_txt, s_tab, out);
             job_or6 = 0u; job_and6 = 0x60u;
             __syncthreads();
             njobs = 0u; job_lanes = 0u; job_T = 0u;
