@@ -7,15 +7,19 @@ namespace strsim {
 
 constexpr int WAVE_CAP = 1024; // wave-per-pair kernels: max bytes (hence scalar values) per string
 
-// k_wave_pairs<LEVENSHTEIN>: pairs advanced together by one wave, and the per-wave global scratch it needs:
-// the three scalar-value arrays of the non-ASCII fallback, then LEV_JOBS staged texts with TXT_PAD bytes around each.
+// k_wave_pairs<LEVENSHTEIN>: up to LEV_JOBS pairs are advanced together by one wave.  Its per-wave global scratch: the
+// three scalar-value arrays of the fallback, then the text arena of a BYTES batch (ASCII texts as bytes), the text
+// arena of a SYMBOLS batch (16-bit scalar values) and the SYMBOLS patterns (32 values per lane); a staged text has
+// TXT_PAD units in front of and behind it.
 #ifndef STRSIM_LEV_JOBS
-#define STRSIM_LEV_JOBS 5
+#define STRSIM_LEV_JOBS 16
 #endif
 constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
-constexpr int TXT_PAD = 64;
-constexpr int TXT_SLOT = WAVE_CAP + 2 * TXT_PAD;
-constexpr int LEV_WS_WORDS = 3 * (WAVE_CAP + 64) + LEV_JOBS * TXT_SLOT / 4; // per wave
+constexpr int TXT_PAD = 48;
+constexpr int ARENA0_BYTES = 8192;
+constexpr int ARENA1_BYTES = 12288;
+constexpr int PAT1_BYTES = 64 * 32 * 2;
+constexpr int LEV_WS_WORDS = 3 * (WAVE_CAP + 64) + (ARENA0_BYTES + ARENA1_BYTES + PAT1_BYTES) / 4; // per wave
 
 struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs

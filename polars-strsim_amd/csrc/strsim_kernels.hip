@@ -24,6 +24,7 @@
 // Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "strsim_lane_core.h"
 #include "strsim_lane_wide.h"
@@ -751,40 +752,64 @@ __device__ __forceinline__ uint32_t bfe_u32(uint32_t w, uint32_t off, uint32_t w
     return (uint32_t)__builtin_amdgcn_ubfe(w, off, width); // width 0 -> 0
 }
 
+// One pair of a batch.  Two kinds of batches: BYTES (both strings ASCII: the pattern is read straight from its column,
+// the text is staged as bytes) and SYMBOLS (any UTF-8 inside the Basic Multilingual Plane: both strings are decoded
+// by the wave and staged as 16-bit scalar values).
 struct BlockJob {
-    const uint8_t *valP; // column holding the pattern (the SHORTER string of the pair)
-    uint32_t p0, m, totalP; // its byte offset / length, and the column's total bytes
-    uint32_t n;          // length of the text (the longer string, staged in LDS)
-    uint32_t seg;        // first lane of the job's run of ceil(m / 32) lanes
-    uint32_t la, lb;     // byte (= scalar value) counts of the row, for the epilogue
-    uint64_t row;
+    uint32_t p0;      // BYTES: byte offset of the pattern (the SHORTER string) in its column
+    uint32_t row;     // row of the frame
+    uint16_t m, n;    // pattern / text length (bytes = scalar values for BYTES, scalar values for SYMBOLS)
+    uint16_t txt;     // the staged text starts at unit 4 * txt of the batch's text arena (front pad included)
+    uint8_t seg;      // first lane of the job's run of ceil(m / 32) lanes
+    uint8_t in_a;     // BYTES: the pattern lives in column A
 };
 
-// Match masks: the masks of the 32 possible values of the low five bits of a byte are tabulated per lane in LDS when
+struct BlockCols { // the two value columns (BYTES batches read their patterns from them)
+    const uint8_t *valA, *valB;
+    uint32_t totalA, totalB;
+};
+
+// Match masks: the masks of the 32 possible values of the low five bits of a symbol are tabulated per lane in LDS when
 // the batch starts (tab[code][lane], 8 KB per wave, each lane writes and reads its own column only), and a step
-// reads its mask instead of computing it; bits 5 and 6 are compared with two bit-planes on top of that (NP == 7)
-// unless they are the same in every byte of the batch (NP == 5; a-z, A-Z, digits ...): 22 / 26 VALU per step.
-template <int NP>
-__device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T,
-                                                const uint8_t *txts, uint32_t *tab, double *__restrict__ out)
+// reads its mask instead of computing it; the higher bits are compared with bit-planes on top of that, as many as
+// vary inside the batch: none for a-z / A-Z / digits (NP = 5), two for general ASCII or one script block (NP = 7),
+// up to bit 10 or bit 15 for mixed scripts / CJK (NP = 11, 16): 22 + 2 * (NP - 5) VALU per step.
+template <int NP, bool SYMBOLS>
+__device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t njobs, uint32_t T, const BlockCols &cols,
+                                                const uint8_t *arena, const uint16_t *pats, uint32_t *tab,
+                                                double *__restrict__ out)
 {
-    static_assert(NP == 5 || NP == 7, "five tabulated planes, plus two computed ones for general ASCII");
+    static_assert(NP == 5 || NP == 7 || NP == 11 || NP == 16, "five tabulated planes plus 0, 2, 6 or 11 computed ones");
+    constexpr int UNIT = SYMBOLS ? 2 : 1; // bytes per text column
     const uint32_t lane = lane_id();
     uint32_t jdx = 0;
-    for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= jobs[q].seg ? 1u : 0u;
-    const uint8_t *valP = jobs[jdx].valP;
-    const uint32_t p0 = jobs[jdx].p0, m = jobs[jdx].m, totalP = jobs[jdx].totalP, n = jobs[jdx].n;
+    for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= (uint32_t)jobs[q].seg ? 1u : 0u;
+    const uint32_t m = jobs[jdx].m, n = jobs[jdx].n;
     const uint32_t blk = lane - jobs[jdx].seg;
-    const uint8_t *txt = txts + jdx * TXT_SLOT; // global scratch, staged by this wave
     const uint32_t B = (m + 31u) >> 5;
     const bool mine = blk < B; // lanes past the last job's run fall into it with blk >= B
-    uint32_t w[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) w[d] = 0u;
-    if (mine) load_window_any<8>(valP, (int64_t)p0 + (int64_t)m - 32 * (int64_t)(B - blk), totalP, w);
-    uint32_t P[NP];
-    build_planes<NP>(w, P);
     const uint32_t s = 32u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..31)
+    uint32_t P[NP];
+    if (SYMBOLS) {
+        // the 32 scalar values of this block were staged end-aligned (zeros in front of the string) at pats[lane * 32]
+        uint32_t w[16];
+        const uint4 *src = reinterpret_cast<const uint4 *>(pats + lane * 32u);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint4 v = mine ? src[d] : make_uint4(0u, 0u, 0u, 0u);
+            w[4 * d] = v.x; w[4 * d + 1] = v.y; w[4 * d + 2] = v.z; w[4 * d + 3] = v.w;
+        }
+        build_planes_sym<NP>([&](int k) { return (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu; }, P);
+    } else {
+        const bool in_a = jobs[jdx].in_a != 0;
+        uint32_t w[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w[d] = 0u;
+        if (mine)
+            load_window_any<8>(in_a ? cols.valA : cols.valB, (int64_t)jobs[jdx].p0 + (int64_t)m - 32 * (int64_t)(B - blk),
+                               in_a ? cols.totalA : cols.totalB, w);
+        build_planes<NP>(w, P);
+    }
     const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
     // Hand-off word of a block: bit 0 = +1, bit 1 = -1 leaving its bottom row.  The LAST block of a job publishes 0
@@ -794,14 +819,22 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published +1 bit
     const uint32_t pubn = blk + 1u == B ? 0u : 2u;  // mask of the published -1 bit
     uint32_t hout = 0u;
-    // Column j = t - blk of the text at step t.  The staged texts have TXT_PAD bytes in front and behind (never used
-    // as columns: a block is idle for blk steps before and at most 32 steps after its own columns), so a lane just
-    // walks on: one (unaligned) dword = four columns per four steps, fetched two dwords ahead.
+    // Column j = t - blk of the text at step t.  A staged text has TXT_PAD units in front and behind (never used as
+    // columns: a block is idle for blk <= 31 steps before its own columns), so a lane just walks on: four columns
+    // per four steps, fetched two trips ahead with one unaligned load; once past its text (the batch runs for the
+    // longest job) the fetch position stops at the rear pad.
     typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    const uint8_t *const col0 = txt + TXT_PAD;
+    typedef uint64_t u64_unaligned __attribute__((aligned(2)));
+    const uint8_t *const col0 = arena + 4u * (uint32_t)jobs[jdx].txt + UNIT * TXT_PAD;
     const uint32_t ncol = mine ? n : 0u;
+    const int32_t jlast = (int32_t)n + TXT_PAD - 4; // last position a four-column fetch may start at
     int32_t j = -(int32_t)blk;
-    auto fetch = [&](int32_t at) { return *reinterpret_cast<const u32_unaligned *>(col0 + at); };
+    using word_t = typename std::conditional<SYMBOLS, uint64_t, uint32_t>::type; // four columns
+    auto fetch = [&](int32_t at) -> word_t {
+        at = at < jlast ? at : jlast;
+        if constexpr (SYMBOLS) return *reinterpret_cast<const u64_unaligned *>(col0 + 2 * at);
+        else return *reinterpret_cast<const u32_unaligned *>(col0 + at);
+    };
     auto step = [&](uint32_t Eq0) {
         const uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
         if ((uint32_t)j < ncol) {
@@ -818,7 +851,7 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
         }
         ++j;
     };
-    uint32_t w0 = fetch(j), w1 = fetch(j + 4);
+    word_t w0 = fetch(j), w1 = fetch(j + 4);
     uint32_t t = 0;
     uint32_t *const trow = tab + lane;
     {
@@ -828,24 +861,34 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
 #pragma unroll
         for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<5>(P5, valid, (uint32_t)code, 0);
     }
-    // mask of the byte `q` of w: table look-up, then the two high planes
-    auto high_planes = [&](uint32_t e, uint32_t w, int q) {
-        if (NP == 7) {
-            e = bitop3<0x90>(e, P[NP - 2], bit_fill(w, 8 * q + 5));
-            e = bitop3<0x90>(e, P[NP - 1], bit_fill(w, 8 * q + 6));
-        }
+    // column q (0..3) of the fetched word: its 32-bit half and the bit its symbol starts at
+    auto half = [&](word_t w, int q) { return SYMBOLS ? (uint32_t)((uint64_t)w >> (32 * (q >> 1))) : (uint32_t)w; };
+    auto bit0 = [&](int q) { return SYMBOLS ? 16 * (q & 1) : 8 * q; };
+    // mask of column q of w: table look-up on the low five bits, then the higher planes
+    auto high_planes = [&](uint32_t e, word_t w, int q) {
+#pragma unroll
+        for (int k = 5; k < NP; ++k) e = bitop3<0x90>(e, P[k], (uint32_t)__builtin_amdgcn_sbfe((int)half(w, q), bit0(q) + k, 1u));
         return e;
     };
-    for (; t + 4u <= T; t += 4u) {
-        const uint32_t w2 = fetch(j + 8);
+    auto trip = [&](word_t w) { // four steps on the four columns of w
         uint32_t e[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(w0, 8u * q, 5u) * 64u];
+        for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(half(w, q), (uint32_t)bit0(q), 5u) * 64u];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) step(high_planes(e[q], w0, q));
-        w0 = w1; w1 = w2;
+        for (int q = 0; q < 4; ++q) step(high_planes(e[q], w, q));
+    };
+    // three words in flight, refilled in turn (no register is copied, so no load is waited for before its turn)
+    word_t w2 = fetch(j + 8);
+    for (; t + 12u <= T; t += 12u) {
+        trip(w0); w0 = fetch(j + 8);
+        trip(w1); w1 = fetch(j + 8);
+        trip(w2); w2 = fetch(j + 8);
     }
-    for (; t < T; ++t, w0 >>= 8) step(high_planes(trow[(w0 & 31u) * 64u], w0, 0));
+    if (t + 4u <= T) {
+        trip(w0); t += 4u; w0 = w1; w1 = w2;
+        if (t + 4u <= T) { trip(w0); t += 4u; w0 = w1; }
+    }
+    for (; t < T; ++t, w0 >>= 8 * UNIT) step(high_planes(trow[((uint32_t)w0 & 31u) * 64u], w0, 0));
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
@@ -864,7 +907,7 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     if (lane < njobs) {
         const int sum = hi_sum - (qseg ? lo_sum : 0);
         const uint32_t dist = (uint32_t)((int)(32u * qB - qm + qn) + sum);
-        out[jobs[q].row] = epilogue_levenshtein(dist, jobs[q].la, jobs[q].lb);
+        out[jobs[q].row] = epilogue_levenshtein(dist, qm, qn);
     }
 }
 
@@ -1041,31 +1084,58 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * LEV_WS_WORDS : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
-    uint8_t *const g_txt = reinterpret_cast<uint8_t *>(aux + (WAVE_CAP + 64)); // LEV: LEV_JOBS staged texts (global)
-    __shared__ BlockJob s_job[LEV ? LEV_JOBS : 1];
+    // LEV: the arenas of the two kinds of batches (global scratch): staged texts as bytes / as 16-bit scalar values,
+    // and the end-aligned 16-bit patterns of a SYMBOLS batch (32 per lane)
+    uint8_t *const g_ar0 = reinterpret_cast<uint8_t *>(aux + (WAVE_CAP + 64));
+    uint8_t *const g_ar1 = g_ar0 + ARENA0_BYTES;
+    uint16_t *const g_pat = reinterpret_cast<uint16_t *>(g_ar1 + ARENA1_BYTES);
+    __shared__ BlockJob s_job[2][LEV ? LEV_JOBS : 1];
     __shared__ uint32_t s_tab[LEV ? 32 * 64 : 1]; // wave_lev_blocks: match masks by code (low five bits) and lane
     __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     uint32_t my_rows = 0, my_huge = 0, my_maxlen = 0;
-    // Levenshtein on ASCII rows: rows are collected until their lane runs fill the wave, then run together
-    uint32_t njobs = 0, job_lanes = 0, job_T = 0;
-    uint32_t job_or6 = 0u, job_and6 = 0x60u; // bits 5/6 over the bytes of the pending jobs
-    auto flush_jobs = [&]() {
+    // Levenshtein: rows are collected into two pending batches (BYTES: both strings ASCII; SYMBOLS: anything else
+    // inside the BMP) until their lane runs, their text arena or their job list is full, then run together
+    struct Batch { uint32_t njobs, lanes, T, used; };
+    Batch bq0{0u, 0u, 0u, 0u}, bq1{0u, 0u, 0u, 0u};
+    uint32_t job_or6 = 0u, job_and6 = 0x60u;   // BYTES: bits 5/6 over the bytes of the pending jobs (wave-uniform)
+    uint32_t sym_or = 0u, sym_and = 0xFFFFu;   // SYMBOLS: OR / AND of the scalar values this lane staged
+    const BlockCols cols{valA, valB, totalA, totalB};
+    auto flush_bytes = [&]() {
         if constexpr (LEV) {
-            if (njobs == 0u) return;
+            if (bq0.njobs == 0u) return;
             // the staged texts were written by this wave's own lanes (plain global stores): the workgroup-scope
             // fence of the barrier orders them before the loads below, and the CU's L1 is coherent for its own waves
             __syncthreads();
             // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
             if ((job_or6 ^ job_and6) & 0x60u)
-                wave_lev_blocks<7>(s_job, njobs, job_T, g_txt, s_tab, out);
+                wave_lev_blocks<7, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
             else
-                wave_lev_blocks<5>(s_job, njobs, job_T, g_txt, s_tab, out);
+                wave_lev_blocks<5, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
             job_or6 = 0u; job_and6 = 0x60u;
             __syncthreads();
-            njobs = 0u; job_lanes = 0u; job_T = 0u;
+            bq0 = Batch{0u, 0u, 0u, 0u};
+        }
+    };
+    auto flush_symbols = [&]() {
+        if constexpr (LEV) {
+            if (bq1.njobs == 0u) return;
+            __syncthreads();
+            uint32_t o = sym_or, n_ = sym_and;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                o |= (uint32_t)__shfl_xor((int)o, d);
+                n_ &= (uint32_t)__shfl_xor((int)n_, d);
+            }
+            const uint32_t vary = uniform((o ^ n_) & 0xFFFFu); // only the bits that differ somewhere need comparing
+            if (vary >> 11) wave_lev_blocks<16, true>(s_job[1], bq1.njobs, bq1.T, cols, g_ar1, g_pat, s_tab, out);
+            else if (vary >> 7) wave_lev_blocks<11, true>(s_job[1], bq1.njobs, bq1.T, cols, g_ar1, g_pat, s_tab, out);
+            else wave_lev_blocks<7, true>(s_job[1], bq1.njobs, bq1.T, cols, g_ar1, g_pat, s_tab, out);
+            sym_or = 0u; sym_and = 0xFFFFu;
+            __syncthreads();
+            bq1 = Batch{0u, 0u, 0u, 0u};
         }
     };
 
@@ -1129,13 +1199,12 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                 todo = nvisit == 64u ? ~0ull : ((1ull << nvisit) - 1ull);
             }
             while (todo != 0ull) {
-              bool full = false;
-              for (unsigned long long scan = todo; scan != 0ull && !full; scan &= scan - 1ull) {
+              for (unsigned long long scan = todo; scan != 0ull; scan &= scan - 1ull) {
                 const uint32_t vi = (uint32_t)__builtin_ctzll(scan);
                 uint32_t bitpos = vi;
                 if (MEASURE == LEVENSHTEIN) {
-                    const uint32_t need = uniform((uint32_t)s_blk[vi]);
-                    if (job_lanes + need > 64u) continue; // no room in this batch
+                    const uint32_t need = uniform((uint32_t)s_blk[vi]); // upper bound: blocks of the shorter BYTE length
+                    if ((bq0.lanes > bq1.lanes ? bq0.lanes : bq1.lanes) + need > 64u) continue; // no room in this pass
                     bitpos = uniform((uint32_t)s_order[vi]);
                 }
                 todo &= ~(1ull << vi);
@@ -1151,35 +1220,100 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     my_maxlen = my_maxlen > ml ? my_maxlen : ml;
                     continue;
                 }
-                if (MEASURE == LEVENSHTEIN && la8 != 0u && lb8 != 0u) {
-                    // shorter string = DP rows (registers, read from global), longer = columns (LDS bytes)
+                if constexpr (LEV) {
+                  if (la8 != 0u && lb8 != 0u) {
+                    // ---- BYTES: shorter string = DP rows (read from its column), longer = columns (staged bytes)
                     const bool a_short = la8 <= lb8;
                     const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
                     const uint32_t Bn = (ms + 31u) >> 5;
                     uint32_t o6 = job_or6, n6 = job_and6;
-                    const bool asc_s = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
-                    const bool asc_l = asc_s && wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, g_txt + njobs * TXT_SLOT + TXT_PAD, o6, n6);
-                    if (asc_l) {
-                        job_or6 = o6; job_and6 = n6;
-                        if (lane == 0u)
-                            s_job[njobs] = a_short ? BlockJob{valA, a0, ms, totalA, nl, job_lanes, la8, lb8, row}
-                                                   : BlockJob{valB, b0, ms, totalB, nl, job_lanes, la8, lb8, row};
-                        ++njobs;
-                        job_lanes += Bn;
-                        const uint32_t Tj = nl + Bn - 1u;
-                        job_T = job_T > Tj ? job_T : Tj;
-                        full = njobs == (uint32_t)LEV_JOBS || job_lanes == 64u;
-                        continue;
+                    bool ascii = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
+                    if (ascii) {
+                        const uint32_t slot = (2u * TXT_PAD + nl + 3u) & ~3u;
+                        if (bq0.njobs == (uint32_t)LEV_JOBS || bq0.lanes + Bn > 64u || bq0.used + slot > (uint32_t)ARENA0_BYTES) {
+                            flush_bytes();
+                            o6 = 0u; n6 = 0x60u;
+                            (void)wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
+                        }
+                        ascii = wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, g_ar0 + bq0.used + TXT_PAD, o6, n6);
+                        if (ascii) {
+                            job_or6 = o6; job_and6 = n6;
+                            if (lane == 0u)
+                                s_job[0][bq0.njobs] = BlockJob{a_short ? a0 : b0, (uint32_t)row, (uint16_t)ms, (uint16_t)nl,
+                                                               (uint16_t)(bq0.used >> 2), (uint8_t)bq0.lanes, (uint8_t)(a_short ? 1 : 0)};
+                            ++bq0.njobs;
+                            bq0.lanes += Bn;
+                            bq0.used += slot;
+                            const uint32_t Tj = nl + Bn - 1u;
+                            bq0.T = bq0.T > Tj ? bq0.T : Tj;
+                            if (bq0.njobs == (uint32_t)LEV_JOBS || bq0.lanes == 64u) flush_bytes();
+                            continue;
+                        }
                     }
+                    // ---- SYMBOLS: decode both strings; the one with fewer scalar values is the pattern
+                    bool nonascii = false;
+                    __syncthreads();
+                    const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
+                    const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
+                    const bool a_pat = la <= lb;
+                    const uint32_t *pat = a_pat ? sA : sB, *txt = a_pat ? sB : sA;
+                    const uint32_t mp = a_pat ? la : lb, nt = a_pat ? lb : la;
+                    const uint32_t Bp = (mp + 31u) >> 5;
+                    const uint32_t slot = (2u * (2u * TXT_PAD + nt) + 3u) & ~3u;
+                    if (bq1.njobs == (uint32_t)LEV_JOBS || bq1.lanes + Bp > 64u || bq1.used + slot > (uint32_t)ARENA1_BYTES)
+                        flush_symbols();
+                    bool big = false;
+                    uint32_t so = sym_or, sn = sym_and;
+                    uint16_t *tdst = reinterpret_cast<uint16_t *>(g_ar1 + bq1.used) + TXT_PAD;
+                    for (uint32_t i = lane; i < nt; i += 64u) {
+                        const uint32_t cp = txt[i];
+                        big = big || cp > 0xFFFFu;
+                        so |= cp; sn &= cp;
+                        tdst[i] = (uint16_t)cp;
+                    }
+                    // the pattern, end-aligned to its last block: zeros stand for the positions in front of it
+                    const uint32_t lead = 32u * Bp - mp;
+                    uint16_t *pdst = g_pat + bq1.lanes * 32u;
+                    for (uint32_t i = lane; i < 32u * Bp; i += 64u) {
+                        uint32_t cp = 0u;
+                        if (i >= lead) {
+                            cp = pat[i - lead];
+                            big = big || cp > 0xFFFFu;
+                            so |= cp; sn &= cp;
+                        }
+                        pdst[i] = (uint16_t)cp;
+                    }
+                    if (__ballot(big) == 0ull) {
+                        sym_or = so & 0xFFFFu; sym_and = sn & 0xFFFFu;
+                        if (lane == 0u)
+                            s_job[1][bq1.njobs] = BlockJob{0u, (uint32_t)row, (uint16_t)mp, (uint16_t)nt, (uint16_t)(bq1.used >> 2),
+                                                           (uint8_t)bq1.lanes, (uint8_t)0};
+                        ++bq1.njobs;
+                        bq1.lanes += Bp;
+                        bq1.used += slot;
+                        const uint32_t Tj = nt + Bp - 1u;
+                        bq1.T = bq1.T > Tj ? bq1.T : Tj;
+                        if (bq1.njobs == (uint32_t)LEV_JOBS || bq1.lanes == 64u) flush_symbols();
+                    } else {
+                        // scalar values beyond the BMP: the anti-diagonal DP on the decoded arrays
+                        const uint32_t dist = wave_levenshtein(sA, la, sB, lb, aux);
+                        if (lane == 0u) out[row] = epilogue_levenshtein(dist, la, lb);
+                    }
+                    continue;
+                  }
                 }
                 const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP);
                 if (lane == 0u) out[row] = r;
               }
-              if (full || todo != 0ull) flush_jobs(); // rows are left that did not fit: run what has been collected
+              if (todo != 0ull) { // rows are left that did not fit: run what has been collected
+                  flush_bytes();
+                  flush_symbols();
+              }
             }
         }
     }
-    flush_jobs();
+    flush_bytes();
+    flush_symbols();
     if (lane == 0u && my_rows != 0u) {
         atomicAdd(&status->wave_rows, my_rows);
         if (my_huge != 0u) {
