@@ -92,8 +92,9 @@ static int ctx_reserve(void **p, size_t *cap, size_t bytes);
 static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
 {
     const uint32_t cap = (st.max_len + 63u) & ~63u;
-    const size_t per_wave = 3u * ((size_t)cap + 64u) * sizeof(uint32_t);
-    size_t waves = st.huge_rows < 512u ? st.huge_rows : 512u;
+    const size_t per_wave = (size_t)HUGE_WS_WORDS(cap) * sizeof(uint32_t);
+    const size_t max_waves = (size_t)c->num_cu * 8u; // two waves per SIMD
+    size_t waves = st.huge_rows < max_waves ? st.huge_rows : max_waves;
     const size_t budget = (size_t)4 << 30; // keep the workspace under 4 GiB
     if (waves * per_wave > budget) waves = budget / per_wave ? budget / per_wave : 1;
     int rc = ctx_reserve((void **)&c->huge_ws, &c->huge_ws_cap, waves * per_wave);

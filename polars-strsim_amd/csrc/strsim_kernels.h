@@ -21,6 +21,9 @@ constexpr int ARENA1_BYTES = 12288;
 constexpr int PAT1_BYTES = 64 * 32 * 2;
 constexpr int LEV_WS_WORDS = 3 * (WAVE_CAP + 64) + (ARENA0_BYTES + ARENA1_BYTES + PAT1_BYTES) / 4; // per wave
 
+// k_huge_pairs: words of global workspace per wave for strings of up to `cap` bytes (a front pad, then three arrays)
+#define HUGE_WS_WORDS(cap) (3u * ((uint64_t)(cap) + 64u) + 64u)
+
 struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs
     unsigned int huge_rows; // rows longer than WAVE_CAP (left for the long-string pass)
@@ -53,7 +56,7 @@ hipError_t launch_pairs(int measure, const LaunchArgs &a);
 // All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
 hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);
 
-// Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with 3 * (cap + 64) words of `ws`.
+// Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with HUGE_WS_WORDS(cap) words of `ws`.
 hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid);
 
 } // namespace strsim

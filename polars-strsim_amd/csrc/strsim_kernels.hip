@@ -911,6 +911,107 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     }
 }
 
+// The same block step for ONE pair of any length (k_huge_pairs): both strings decoded to 32-bit scalar values in the
+// global workspace, the pattern (the one with fewer values) cut into stripes of 64 blocks = 2048 rows that run one
+// after the other over all the columns.  The bottom-row deltas of a stripe go through a byte array hb[column]
+// (global, written by the stripe's last block 63 steps after block 0 of the same stripe consumed the entry the
+// previous stripe left there); the distance is s + n + the vertical deltas of every block at its last column.
+// txt[-TXT_PAD .. n + TXT_PAD) and hb[-TXT_PAD .. n + TXT_PAD) must be readable.  Scalar values <= 0xFFFF.
+template <int NP>
+__device__ __forceinline__ uint32_t wave_lev_stripes(const uint32_t *pat, uint32_t m, const uint32_t *txt, uint32_t n,
+                                                     uint8_t *hb, uint32_t *tab)
+{
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    struct u32x4 { uint32_t v[4]; };
+    const uint32_t lane = lane_id();
+    const uint32_t Btot = (m + 31u) >> 5;
+    const uint32_t s = 32u * Btot - m;
+    int total = 0;
+    uint32_t *const trow = tab + lane;
+    const int32_t jlast = (int32_t)n + TXT_PAD - 4;
+    for (uint32_t g0 = 0; g0 < Btot; g0 += 64u) {
+        const uint32_t nb = Btot - g0 < 64u ? Btot - g0 : 64u;
+        const bool mine = lane < nb;
+        const uint32_t g = g0 + lane;
+        const bool later = g0 != 0u;            // block 0 of this stripe is fed from hb[]
+        const bool more = g0 + 64u < Btot;      // the last block of this stripe feeds hb[]
+        uint32_t w[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int64_t idx = (int64_t)g * 32 - (int64_t)s + k;
+            w[k] = (mine && idx >= 0) ? pat[idx] : 0u;
+        }
+        uint32_t P[NP];
+        build_planes_sym<NP>([&](int k) { return w[k] & 0xFFFFu; }, P);
+        const uint32_t valid = g == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
+        uint32_t Pv = valid, Mv = ~valid;
+        const uint32_t first = g == 0u ? 1u : 0u;
+        const uint32_t pubw = g + 1u == Btot ? 0u : 1u;
+        const uint32_t pubn = g + 1u == Btot ? 0u : 2u;
+        uint32_t hout = 0u;
+        {
+            uint32_t P5[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) P5[k] = P[k];
+#pragma unroll
+            for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<5>(P5, valid, (uint32_t)code, 0);
+        }
+        const uint32_t ncol = mine ? n : 0u;
+        const bool feeder = more && lane + 1u == nb;
+        int32_t j = -(int32_t)lane;
+        auto clampj = [&](int32_t at) { return at < jlast ? at : jlast; };
+        auto fetch_t = [&](int32_t at) { return *reinterpret_cast<const u32x4 *>(txt + clampj(at)); };
+        auto fetch_h = [&](int32_t at) { return *reinterpret_cast<const u32_unaligned *>(hb + clampj(at)); };
+        const uint32_t T = n + nb - 1u;
+        auto trip = [&](const u32x4 &wt, uint32_t wh, uint32_t t) { // four steps on the four columns of wt
+            uint32_t e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = trow[(wt.v[q] & 31u) * 64u];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+                if (later && lane == 0u) hin = (wh >> (8 * q)) & 3u;
+                if (t + (uint32_t)q < T && (uint32_t)j < ncol) {
+                    uint32_t Eq0 = e[q];
+#pragma unroll
+                    for (int k = 5; k < NP; ++k) Eq0 = bitop3<0x90>(Eq0, P[k], bit_fill(wt.v[q], k));
+                    const uint32_t hinP = (hin & 1u) | first, hinN = hin >> 1;
+                    const uint32_t Xv = Eq0 | Mv;
+                    const uint32_t Eq = Eq0 | hinN;
+                    const uint32_t Xh = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq);
+                    const uint32_t Ph = bitop3<0xF1>(Mv, Xh, Pv);
+                    const uint32_t Mh = Pv & Xh;
+                    hout = bfe_u32(Ph, 31u, pubw) | ((Mh >> 30) & pubn);
+                    const uint32_t PhS = (Ph << 1) | hinP, MhS = (Mh << 1) | hinN;
+                    Pv = bitop3<0xF1>(MhS, Xv, PhS);
+                    Mv = PhS & Xv;
+                    if (feeder) hb[j] = (uint8_t)hout;
+                }
+                ++j;
+            }
+        };
+        // two words in flight, refilled in turn one trip ahead of their use
+        u32x4 ta = fetch_t(j), tb = fetch_t(j + 4);
+        uint32_t ha = later ? fetch_h(j) : 0u, hc = later ? fetch_h(j + 4) : 0u; // only lane 0 uses them
+        for (uint32_t t = 0; t < T; t += 8u) {
+            trip(ta, ha, t);
+            ta = fetch_t(j + 4);
+            if (later) ha = fetch_h(j + 4);
+            if (t + 4u < T) {
+                trip(tb, hc, t + 4u);
+                tb = fetch_t(j + 4);
+                if (later) hc = fetch_h(j + 4);
+            }
+        }
+        int v = mine ? (int)popc32(Pv) - (int)popc32(Mv) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        total += v;
+        __syncthreads(); // hb[] written by this stripe is read by the next one (same wave; see flush_bytes)
+    }
+    return (uint32_t)((int)(s + n) + total);
+}
+
 // Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
 // or6/and6 accumulate, wave-uniformly, whether bits 5 and 6 are set in any / in every byte (plane-count choice).
 __device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ p, uint32_t len, uint8_t *dst, uint32_t &or6,
@@ -1323,6 +1424,43 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     }
 }
 
+// Levenshtein similarity of one pair of any length (k_huge_pairs): decode, then the striped block kernel with as many
+// bit-planes as the pair's scalar values need; values beyond the BMP fall back to the anti-diagonal DP.
+__device__ __forceinline__ double huge_levenshtein(const uint8_t *__restrict__ pa, uint32_t la8, const uint8_t *__restrict__ pb,
+                                                   uint32_t lb8, uint32_t *sA, uint32_t *sB, uint32_t *aux, uint32_t *tab)
+{
+    const uint32_t lane = lane_id();
+    if (la8 == 0u && lb8 == 0u) return 1.0;
+    if (la8 == 0u || lb8 == 0u) return 0.0;
+    bool nonascii = false;
+    __syncthreads();
+    const uint32_t la = wave_decode(pa, la8, sA, nonascii);
+    const uint32_t lb = wave_decode(pb, lb8, sB, nonascii);
+    uint32_t o = 0u, a_ = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < la; i += 64u) { o |= sA[i]; a_ &= sA[i]; }
+    for (uint32_t i = lane; i < lb; i += 64u) { o |= sB[i]; a_ &= sB[i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        o |= (uint32_t)__shfl_xor((int)o, d);
+        a_ &= (uint32_t)__shfl_xor((int)a_, d);
+    }
+    o = uniform(o);
+    const uint32_t vary = uniform(o ^ a_);
+    uint32_t dist;
+    if (o > 0xFFFFu) {
+        dist = wave_levenshtein(sA, la, sB, lb, aux);
+    } else {
+        const bool a_pat = la <= lb;
+        const uint32_t *pat = a_pat ? sA : sB, *txt = a_pat ? sB : sA;
+        const uint32_t m = a_pat ? la : lb, n = a_pat ? lb : la;
+        uint8_t *hb = reinterpret_cast<uint8_t *>(aux) + 64;
+        if (vary >> 11) dist = wave_lev_stripes<16>(pat, m, txt, n, hb, tab);
+        else if (vary >> 7) dist = wave_lev_stripes<11>(pat, m, txt, n, hb, tab);
+        else dist = wave_lev_stripes<7>(pat, m, txt, n, hb, tab);
+    }
+    return epilogue_levenshtein(dist, la, lb);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_huge_pairs: rows with a string longer than WAVE_CAP bytes, same algorithms with the scratch arrays in a
 // global-memory workspace (3 * (cap + 64) words per wave).  Launched only when k_wave_pairs counted such rows.
@@ -1337,9 +1475,11 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
-    uint32_t *sA = ws + (uint64_t)blockIdx.x * 3u * ((uint64_t)cap + 64u);
+    // per wave: 64 words of front pad (wave_lev_stripes reads a little in front of its text), then the three arrays
+    uint32_t *sA = ws + (uint64_t)blockIdx.x * HUGE_WS_WORDS(cap) + 64u;
     uint32_t *sB = sA + cap + 64u;
     uint32_t *aux = sB + cap + 64u;
+    __shared__ uint32_t s_tab[MEASURE == LEVENSHTEIN ? 32 * 64 : 1];
     for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n; base += (uint64_t)gridDim.x * 64u) {
         const uint64_t rmine = base + lane;
         bool big = false;
@@ -1355,7 +1495,11 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
             const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
             const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
             const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
-            const double r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap);
+            double r;
+            if constexpr (MEASURE == LEVENSHTEIN)
+                r = huge_levenshtein(valA + a0, a1 - a0, valB + b0, b1 - b0, sA, sB, aux, s_tab);
+            else
+                r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap);
             if (lane == 0u) out[row] = r;
         }
     }

@@ -217,6 +217,28 @@ def test_strings_beyond_the_wave_kernel_cap(S, ctx, measure):
     assert_bit_exact(got, O.batch_strings(measure, A[:50], B[:50]), A[:50], B[:50], measure)
 
 
+def test_very_long_levenshtein_stripes(S, ctx):
+    """Levenshtein beyond 1024 bytes: the striped block kernel (patterns of more than 2048 scalar values take several
+    stripes), ASCII / one script / mixed scripts (7, 11 and 16 planes) / astral values (anti-diagonal fallback)."""
+    import random
+    rng = random.Random(43)
+    cyr = "".join(chr(c) for c in range(0x430, 0x450))
+    cjk = "".join(chr(c) for c in range(0x4E00, 0x4E80)) + cyr + gen.ASCII_LOWER
+    specs = [(1025, 1030, gen.ASCII_LOWER), (2047, 2048, gen.ASCII_LOWER), (2049, 2049, "ab"), (4100, 4500, gen.ASCII_LOWER),
+             (6200, 2100, gen.ASCII_LOWER + "XYZ ,."), (700, 700, cyr), (2100, 2300, cyr), (1500, 900, cyr + gen.ASCII_LOWER),
+             (2500, 2500, cjk), (33, 5000, cyr), (1200, 1300, cyr + "\U0001F600"), (4097, 1, "a"), (3000, 3000, "a")]
+    A, B = [], []
+    for la, lb, alpha in specs:
+        a = "".join(rng.choice(alpha) for _ in range(la))
+        b = gen.edit(rng, a, alpha, 7) if la == lb else "".join(rng.choice(alpha) for _ in range(lb))
+        A.append(a)
+        B.append(b)
+    got = gpu(S, ctx, "levenshtein", A, B)
+    assert_bit_exact(got, O.batch_strings("levenshtein", A, B, 8), A, B, "levenshtein")
+    got = gpu(S, ctx, "levenshtein", B, A)
+    assert_bit_exact(got, O.batch_strings("levenshtein", B, A, 8), B, A, "levenshtein")
+
+
 def test_shape_mismatch(S, ctx):
     with pytest.raises(S.ShapeMismatch, match="Inputs must have the same length, or one of them must be a Utf8 literal."):
         gpu(S, ctx, "jaro", ["a", "b"], ["a", "b", "c"])
