@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_IN
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 cd "$ROOT"
-python3 bench_support/summarize_profile.py "$OUT" ${TRAFFIC_KEY:-} > "$OUT/summary.txt" 2>&1
+python3 bench_support/summarize_profile.py "$OUT" ${TRAFFIC_KEY:-} ${TRAFFIC_KERNEL:-} > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

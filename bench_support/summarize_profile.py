@@ -17,9 +17,10 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-def traffic_json(out, key):
-    """HBM bytes per launch of k_lane_pairs: FETCH_SIZE (KiB, doubled: gfx950 reports half of a wide coalesced
-    read -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB), each from its own --pmc pass."""
+def traffic_json(out, key, kernel="k_lane_pairs"):
+    """HBM bytes per launch of the dominant kernel (name contains `kernel`): FETCH_SIZE (KiB, doubled: gfx950 reports
+    half of a wide coalesced read -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB), each from its own --pmc pass.
+    key = "<config>:<measure>:<rows per GPU>", the key bench.py looks up."""
     import json
     vals = {}
     for grp, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -27,13 +28,14 @@ def traffic_json(out, key):
         if not f:
             return
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-             if "k_lane_pairs" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+             if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr]
         if not v:
             return
         vals[ctr] = sum(v) / len(v)
     rec = {"fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
            "traffic_bytes_per_launch": int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
-           "source": os.path.basename(out)}
+           "kernel": kernel, "source": os.path.basename(out)}
+    json.dump({key: rec}, open(os.path.join(out, "traffic_record.json"), "w"), indent=1)  # travels back in gpurun_out/
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
     try:
         db = json.load(open(path))
@@ -47,7 +49,7 @@ def traffic_json(out, key):
 def main():
     out = sys.argv[1]
     if len(sys.argv) > 2:
-        traffic_json(out, sys.argv[2])
+        traffic_json(out, sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "k_lane_pairs")
     st = find(os.path.join(out, "trace"), "*kernel_stats.csv")
     if st:
         print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
