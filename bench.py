@@ -223,7 +223,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             key = f"{a.config}:{measures[0]}:{rows}"
             if len(measures) == 1 and key in tj:
-                traffic = tj[key]["traffic_bytes_per_launch"]
+                traffic = tj[key]["traffic_bytes_per_launch"] * nparts  # per pass over the whole shard, like `achieved`
         except Exception:
             pass
         # the dominant kernel: k_lane_pairs, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
