@@ -14,11 +14,13 @@
 //                     (strsim_lane_wide.h), text in an LDS column per lane.
 //   k_lane_utf8<M>    ONE PAIR PER LANE, short non-ASCII strings (<= 32 scalar values, BMP): per-lane UTF-8 decode
 //                     into 16-bit symbols in LDS, then the same cores on symbols (strsim_lane_sym.h).
-//   k_wave_pairs<M>   ONE PAIR PER WAVE (TWO for ASCII Levenshtein) for the rest, up to WAVE_CAP bytes, any UTF-8:
-//                     strings decoded to Unicode scalar values in LDS (the reference works on `char`s,
-//                     strsim.rs:133,189,297); block-parallel Myers across lanes / anti-diagonal DP / ballot matching.
-//   k_huge_pairs<M>   the same per-row code with its scratch in global memory, for strings beyond WAVE_CAP;
-//                     launched from strsim_ctx_synchronize() only when such rows were counted.
+//   k_wave_pairs<M>   the rest, up to WAVE_CAP bytes, any UTF-8, taken chunk by chunk from a work list k_lane_utf8 builds.
+//                     Levenshtein: up to 16 pairs per wave in runs of lanes, block-parallel Myers (one 32-row block per
+//                     lane, DPP hand-off), match masks from a per-lane LDS table, texts in a global arena; on bytes
+//                     (ASCII) or on 16-bit scalar values (the reference works on `char`s, strsim.rs:133,189,297).
+//                     Other measures: one pair per wave, scalar values in LDS, ballot matching / histograms.
+//   k_huge_pairs<M>   strings beyond WAVE_CAP, scratch in global memory, launched from strsim_ctx_synchronize() only
+//                     when such rows were counted; Levenshtein: the block step in stripes of 64 blocks, any length.
 //
 // No MFMA anywhere: this is integer/byte work whose roofline is HBM bytes.
 // Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
                                                           const uint32_t *__restrict__ offB,
                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                           double *__restrict__ out, uint64_t n,
-                                                          unsigned long long *__restrict__ slowmask)
+                                                          unsigned long long *__restrict__ slowmask, uint32_t sps)
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
     __shared__ uint32_t s_cnt[16];              // rows per key = width class (2) x column-count bucket (8)
@@ -386,13 +388,15 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__rest
 
     // Super-spans of WIDE_BLOCK mask words (one per thread, coalesced): a workgroup-wide OR decides whether
     // any of its WIDE_BLOCK / WIDE_SPAN spans needs work at all -- the common all-clear case costs one barrier.
-    constexpr int SPANS_PER_SUPER = WIDE_BLOCK / WIDE_SPAN;
-    const uint64_t nsuper = (nspans + SPANS_PER_SUPER - 1) / SPANS_PER_SUPER;
+    // sps spans per super (1 .. WIDE_BLOCK / WIDE_SPAN, chosen by the launcher so that a mid-size frame still makes
+    // enough workgroups to fill the chip)
+    const uint64_t nsuper = (nspans + sps - 1) / sps;
+    const uint32_t super_words = sps * (uint32_t)WIDE_SPAN;
     for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-      const uint64_t cw = sup * WIDE_BLOCK + tid;
-      const unsigned long long myword = cw < nchunks ? slowmask[cw] : 0ull;
+      const uint64_t cw = sup * super_words + tid;
+      const unsigned long long myword = (tid < super_words && cw < nchunks) ? slowmask[cw] : 0ull;
       if (!__syncthreads_or(myword != 0ull)) continue;
-      for (uint64_t span = sup * SPANS_PER_SUPER; span < (sup + 1) * SPANS_PER_SUPER && span < nspans; ++span) {
+      for (uint64_t span = sup * sps; span < (sup + 1) * sps && span < nspans; ++span) {
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 16u) s_cnt[tid] = 0u;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                                                           const uint32_t *__restrict__ offB,
                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                           double *__restrict__ out, uint64_t n,
-                                                          unsigned long long *__restrict__ slowmask,
+                                                          unsigned long long *__restrict__ slowmask, uint32_t sps,
                                                           uint32_t *__restrict__ worklist, DevStatus *__restrict__ status)
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
@@ -525,14 +529,16 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
     const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
-    constexpr int SPANS_PER_SUPER = WIDE_BLOCK / WIDE_SPAN;
-    const uint64_t nsuper = (nspans + SPANS_PER_SUPER - 1) / SPANS_PER_SUPER;
+    // sps spans per super (1 .. WIDE_BLOCK / WIDE_SPAN, chosen by the launcher so that a mid-size frame still makes
+    // enough workgroups to fill the chip)
+    const uint64_t nsuper = (nspans + sps - 1) / sps;
+    const uint32_t super_words = sps * (uint32_t)WIDE_SPAN;
 
     for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-      const uint64_t cw = sup * WIDE_BLOCK + tid;
-      const unsigned long long myword = cw < nchunks ? slowmask[cw] : 0ull;
+      const uint64_t cw = sup * super_words + tid;
+      const unsigned long long myword = (tid < super_words && cw < nchunks) ? slowmask[cw] : 0ull;
       if (!__syncthreads_or(myword != 0ull)) continue;
-      for (uint64_t span = sup * SPANS_PER_SUPER; span < (sup + 1) * SPANS_PER_SUPER && span < nspans; ++span) {
+      for (uint64_t span = sup * sps; span < (sup + 1) * sps && span < nspans; ++span) {
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 8u) s_cnt[tid] = 0u;
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
       }
       // This is the last per-lane kernel: the chunks that still hold rows go onto k_wave_pairs' work list
       // (order irrelevant), with their count and their rows for its work distribution.
-      const unsigned long long fin = cw < nchunks ? *reinterpret_cast<const volatile unsigned long long *>(slowmask + cw) : 0ull;
+      const unsigned long long fin = (tid < super_words && cw < nchunks) ? *reinterpret_cast<const volatile unsigned long long *>(slowmask + cw) : 0ull;
       const unsigned long long bal = __ballot(fin != 0ull);
       if (bal != 0ull) {
           uint32_t rows = (uint32_t)__popcll(fin);
@@ -1144,7 +1150,7 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
     const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
     double r;
     if (MEASURE == LEVENSHTEIN) {
-        // (ASCII rows up to WAVE_CAP bytes never get here: k_wave_pairs runs them two at a time in wave_lev_blocks2)
+        // (k_wave_pairs<LEVENSHTEIN> only gets here for an empty side; everything else runs in wave_lev_blocks)
         const uint32_t dist = wave_levenshtein(sA, la, sB, lb, aux);
         r = epilogue_levenshtein(dist, la, lb);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
@@ -1175,9 +1181,9 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ worklist,
                                                    DevStatus *__restrict__ status, uint32_t *__restrict__ lev_ws)
 {
-    // Levenshtein: the ASCII rows (the common case) run in wave_lev_blocks2, which is latency-bound and only needs the
-    // two staged byte strings in LDS -- so the scalar-value scratch of the non-ASCII fallback lives in a global
-    // workspace (lev_ws, 3 * (WAVE_CAP + 64) words per wave) and LDS no longer caps the kernel at 10 waves per CU.
+    // Levenshtein runs in wave_lev_blocks, whose step loop needs occupancy more than anything: LDS holds only its
+    // match table (8 KB), everything else -- staged texts, the scalar-value arrays of the fallback -- lives in a per-wave
+    // global workspace (lev_ws, LEV_WS_WORDS words per wave).
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     __shared__ uint32_t sA_l[LEV ? 1 : WAVE_CAP];
     __shared__ uint32_t sB_l[LEV ? 1 : WAVE_CAP];
@@ -1508,6 +1514,22 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// k_lane_wide / k_lane_utf8 geometry: spans (32 mask words) per super-span and workgroups.  A super is what one
+// workgroup tests for "anything to do" with a single barrier; full-size frames use the largest (8 spans), smaller
+// ones shrink it until there are about two supers per resident workgroup.
+static void wide_geometry(const LaunchArgs &a, uint32_t &sps, unsigned &grid)
+{
+    const uint64_t nchunks = (a.n + 63u) >> 6;
+    const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
+    const uint64_t want = 2u * (uint64_t)a.wide_grid;
+    uint64_t k = nspans / (want ? want : 1u);
+    if (k < 1u) k = 1u;
+    if (k > (uint64_t)(WIDE_BLOCK / WIDE_SPAN)) k = WIDE_BLOCK / WIDE_SPAN;
+    sps = (uint32_t)k;
+    const uint64_t nsuper = (nspans + k - 1u) / k;
+    grid = (unsigned)(nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid);
+}
+
 template <int M>
 static void launch_pair(const LaunchArgs &a)
 {
@@ -1523,12 +1545,13 @@ static void launch_pair(const LaunchArgs &a)
                        a.valB, a.rowsB, op, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
-        const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
-        const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
-        hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask);
-        hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status);
+        uint32_t sps;
+        unsigned g3;
+        wide_geometry(a, sps, g3);
+        hipLaunchKernelGGL((k_lane_wide<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, sps);
+        hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, sps, a.worklist, a.status);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
@@ -1559,14 +1582,15 @@ template <int M>
 static void launch_slow_kernels(const LaunchArgs &a, double *out)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
-    const uint64_t nsuper = (nchunks + WIDE_BLOCK - 1) / WIDE_BLOCK;
-    const uint64_t g3 = nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid;
+    uint32_t sps;
+    unsigned g3;
+    wide_geometry(a, sps, g3);
     const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev : (uint64_t)a.wave_grid;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
-    hipLaunchKernelGGL((k_lane_wide<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask);
-    hipLaunchKernelGGL((k_lane_utf8<M>), dim3((unsigned)g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask, a.worklist, a.status);
+    hipLaunchKernelGGL((k_lane_wide<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask, sps);
+    hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask, sps, a.worklist, a.status);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
 }
