@@ -91,14 +91,16 @@ constexpr int LANE_ROUNDS = 2 * LANE_WAVES;      // 8 rounds of 64 rows per bloc
 constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
 constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coalesced phases (2)
 
-// 4 * ceil(max over the wave of v / 4), at least 4 (v <= 32): three ballots, result in an SGPR
+// COLS_PER_TEST * ceil(max over the wave of v / COLS_PER_TEST), at least COLS_PER_TEST (v <= 32): a binary search
+// with ballots, result in an SGPR
 __device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
 {
-    uint32_t g = 0;
-    if (__ballot(v > 16u) != 0ull) g = 4;
-    if (__ballot(v > 4u * (g + 2u)) != 0ull) g += 2;
-    if (__ballot(v > 4u * (g + 1u)) != 0ull) g += 1;
-    return 4u * (g + 1u);
+    constexpr uint32_t C = (uint32_t)COLS_PER_TEST;
+    uint32_t g = 0; // groups of C columns below the answer
+#pragma unroll
+    for (uint32_t half = 16u / C; half >= 1u; half >>= 1)
+        if (__ballot(v > C * (g + half)) != 0ull) g += half;
+    return C * (g + 1u);
 }
 
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation

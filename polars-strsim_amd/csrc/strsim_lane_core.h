@@ -26,6 +26,14 @@ namespace strsim {
 
 enum Measure : int { LEVENSHTEIN = 0, JARO = 1, JARO_WINKLER = 2, JACCARD = 3, SORENSEN_DICE = 4 };
 
+// The per-column loops of the cores are fully unrolled and leave at a lane-uniform bound (tmax) that is tested every
+// COLS_PER_TEST columns: a round of 64 pairs runs its longest text rounded up to that (cfg2: 17.5 columns per pair
+// with 4, 16.3 with 2, 13.9 needed).
+#ifndef STRSIM_COLS_PER_TEST
+#define STRSIM_COLS_PER_TEST 2
+#endif
+constexpr int COLS_PER_TEST = STRSIM_COLS_PER_TEST;
+
 STRSIM_HD uint32_t lane_byte(const uint32_t (&w)[8], int j) { return (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu; }
 
 STRSIM_HD uint32_t low_ones(uint32_t k) { return k >= 32u ? 0xFFFFFFFFu : ((1u << k) - 1u); }
@@ -200,11 +208,12 @@ STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tm
     uint32_t hp = 0u, hn = 0u;
     uint32_t nit = 0u;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if ((uint32_t)(4 * g) >= tmax) break;
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const uint32_t Eq = eq_mask<NP>(P, valid, wt[g], jj);
+        for (int jj = 0; jj < COLS_PER_TEST; ++jj) {
+            const int j = COLS_PER_TEST * g + jj;
+            const uint32_t Eq = eq_mask<NP>(P, valid, wt[j >> 2], j & 3);
             const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq | Mv); // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
             const uint32_t HP = bitop3<0xF1>(Mv, D0, Pv);                    // Mv | ~(D0 | Pv)
             const uint32_t HN = Pv & D0;
@@ -214,7 +223,7 @@ STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tm
             Pv = bitop3<0xF1>(HN << 1, D0, X);                               // (HN << 1) | ~(D0 | X)
             Mv = D0 & X;
         }
-        nit += 4u;
+        nit += (uint32_t)COLS_PER_TEST;
     }
     // column j sits at history bit nit-1-j; keep columns 0..lt-1
     const uint32_t cols = low_ones(lt) << (nit - lt);
@@ -242,12 +251,12 @@ STRSIM_HD void jaro_match32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmax,
     uint32_t lomask = 0u;                                              // ones below max(0, i-bound)
     uint32_t fb = 0u, fa = 0u;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if ((uint32_t)(4 * g) >= tmax) break;
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * g + ii;
-            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[g], ii);
+        for (int ii = 0; ii < COLS_PER_TEST; ++ii) {
+            const int i = COLS_PER_TEST * g + ii;
+            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[i >> 2], i & 3);
             const uint32_t cand = Eq & himask & ~(lomask | fb) & bit_fill(live, i);
             const uint32_t bit = cand & (0u - cand);
             fb |= bit;
@@ -259,15 +268,15 @@ STRSIM_HD void jaro_match32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmax,
     uint32_t t = 0u;
     uint32_t rest = fb;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if ((uint32_t)(4 * g) >= tmax) break;
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * g + ii;
+        for (int ii = 0; ii < COLS_PER_TEST; ++ii) {
+            const int i = COLS_PER_TEST * g + ii;
             const uint32_t on = bit_fill(fa, i);               // a_i was matched
             const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
             rest ^= jbit;
-            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[g], ii);
+            const uint32_t Eq = eq_mask<NP>(P, lbmask, wa[i >> 2], i & 3);
             t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
         }
     }
@@ -302,11 +311,12 @@ STRSIM_HD uint32_t multiset_isect32(const uint32_t (&wa)[8], uint32_t la, uint32
     const uint32_t live = low_ones(la);
     uint32_t used = 0u;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if ((uint32_t)(4 * g) >= tmax) break;
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t cand = eq_mask<NP>(P, lbmask, wa[g], ii) & ~used & bit_fill(live, 4 * g + ii);
+        for (int ii = 0; ii < COLS_PER_TEST; ++ii) {
+            const int i = COLS_PER_TEST * g + ii;
+            const uint32_t cand = eq_mask<NP>(P, lbmask, wa[i >> 2], i & 3) & ~used & bit_fill(live, i);
             used |= cand & (0u - cand);
         }
     }
@@ -373,7 +383,15 @@ STRSIM_HD double lane_pair_result(const uint32_t (&wa)[8], uint32_t la, const ui
         const uint32_t s = 32u - lb1;
 #pragma unroll
         for (int k = 0; k < NP; ++k) P[k] <<= s;
+#if defined(STRSIM_EXP_NODP)
+        uint32_t dist = P[0] & 31u; // experiment: everything but the DP loop
+        (void)tmax;
+#elif defined(STRSIM_EXP_NOPLANES)
+        uint32_t dist = (wb[0] ^ wa[0]) & 31u; // experiment: neither planes nor DP
+        (void)tmax;
+#else
         const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
+#endif
         r = levtab ? levtab[dist * 33u + (la1 > lb1 ? la1 : lb1)] : epilogue_levenshtein(dist, la1, lb1);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
