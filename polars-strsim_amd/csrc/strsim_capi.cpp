@@ -53,7 +53,7 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
-    int lane_wg_per_cu = 5; // STRSIM_LANE_WG_PER_CU overrides (tuning knob)
+    int lane_wg_per_cu = 6; // STRSIM_LANE_WG_PER_CU overrides (tuning knob); 6 x 4 waves = 6 per SIMD
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;

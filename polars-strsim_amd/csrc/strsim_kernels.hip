@@ -103,14 +103,29 @@ __device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
     return C * (g + 1u);
 }
 
+#ifndef STRSIM_LANE_PREFETCH
+#define STRSIM_LANE_PREFETCH 0
+#endif
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
 
 struct OutPtrs {
     double *p[5]; // indexed by Measure; single-measure kernels use p[0]
 };
 
+// Register budget of k_lane_pairs: left alone the compiler takes 86 (Levenshtein) to 114 (Jaro) VGPRs = 5 / 4 waves
+// per SIMD; asked for 6 it fits 80 with 1-4 spilled registers outside the column loops (cfg2 on one box: Levenshtein
+// 2.30 -> 2.26 ms, Jaro 3.46 -> 3.21 ms; 7 and 8 waves lose again).  Goes with 6 workgroups per CU (strsim_capi.cpp).
+#ifndef STRSIM_LANE_WAVES_PER_EU
+#define STRSIM_LANE_WAVES_PER_EU 6
+#endif
+#if STRSIM_LANE_WAVES_PER_EU
+#define LANE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(STRSIM_LANE_WAVES_PER_EU)))
+#else
+#define LANE_OCCUPANCY
+#endif
+
 template <int MEASURE>
-__global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__restrict__ offA,
+__global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const uint32_t *__restrict__ offA,
                                                            const uint8_t *__restrict__ valA, uint64_t rowsA,
                                                            const uint32_t *__restrict__ offB,
                                                            const uint8_t *__restrict__ valB, uint64_t rowsB,
@@ -192,12 +207,13 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
         __syncthreads();
 
         // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
+        // the windows of a round are fetched while the round before it computes (a wave's two rounds, software-pipelined)
+        struct RoundIn { uint32_t idx, la8, lb8; bool fast; };
+        auto fetch_round = [&](int rr, RoundIn &in, uint32_t (&wa)[8], uint32_t (&wb)[8]) {
             const uint32_t r = rr ? (uint32_t)(LANE_ROUNDS - 1) - wv : wv;
             const uint32_t idx = s_perm[r * 64u + lane];
             const uint32_t len = s_len[idx];
-            bool fast = len != 0xFFFFFFFFu;
+            const bool fast = len != 0xFFFFFFFFu;
             uint32_t la8 = fast ? (len & 0xFFFFu) : 0u, lb8 = fast ? (len >> 16) : 0u;
             // symmetric measures walk the shorter string: pick the roles BEFORE loading (no register swap);
             // rows this kernel skips read a harmless window at offset 0
@@ -207,9 +223,27 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
             uint32_t t0 = swap ? s_b0[idx] : s_a0[idx], p0 = swap ? s_a0[idx] : s_b0[idx];
             if (!fast) { t0 = 0u; p0 = 0u; }
             if (swap) { const uint32_t t = la8; la8 = lb8; lb8 = t; }
-            uint32_t wa[8], wb[8];
             load_window32(vT, t0, tT, wa);
             load_window32(vP, p0, tP, wb);
+            in = RoundIn{idx, la8, lb8, fast};
+        };
+        RoundIn cur;
+        uint32_t wa[8], wb[8];
+        fetch_round(0, cur, wa, wb);
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            RoundIn nxt = cur;
+            uint32_t na[8], nb[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { na[d] = 0u; nb[d] = 0u; }
+#if STRSIM_LANE_PREFETCH
+            if (rr == 0) fetch_round(1, nxt, na, nb);
+#else
+            if (rr == 1) fetch_round(1, cur, wa, wb);
+#endif
+            const uint32_t idx = cur.idx;
+            bool fast = cur.fast;
+            const uint32_t la8 = cur.la8, lb8 = cur.lb8;
             // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any
             // high bit sends the row to the code-point kernel; the varying low bits decide how many bit-planes
             // the match masks need
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
                 fast = false;
                 atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
             }
-            if (__ballot(fast) == 0ull) continue;
+            if (__ballot(fast) != 0ull) {
             const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
             const uint32_t tmax = wave_max_round4(la);
             const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
@@ -241,6 +275,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_lane_pairs(const uint32_t *__res
                 else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab);
                 if (fast) s_out[0][idx] = res;
             }
+            }
+            cur = nxt;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { wa[d] = na[d]; wb[d] = nb[d]; }
         }
         __syncthreads();
         // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
