@@ -21,8 +21,10 @@ constexpr int ARENA1_BYTES = 12288;
 constexpr int PAT1_BYTES = 64 * 32 * 2;
 constexpr int LEV_WS_WORDS = 3 * (WAVE_CAP + 64) + (ARENA0_BYTES + ARENA1_BYTES + PAT1_BYTES) / 4; // per wave
 
-// k_huge_pairs: words of global workspace per wave for strings of up to `cap` bytes (a front pad, then three arrays)
-#define HUGE_WS_WORDS(cap) (3u * ((uint64_t)(cap) + 64u) + 64u)
+// k_huge_pairs: words of global workspace per wave for strings of up to `cap` bytes: a front pad, the two arrays of
+// scalar values, and an auxiliary array four times as long (hash table of the multiset intersection: 2 (cap + 64)
+// 64-bit entries; Jaro flags; Levenshtein hand-off bytes)
+#define HUGE_WS_WORDS(cap) (6u * ((uint64_t)(cap) + 64u) + 64u)
 
 struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs

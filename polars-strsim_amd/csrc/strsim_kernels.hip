@@ -1143,8 +1143,59 @@ __device__ __forceinline__ void wave_jaro(uint32_t *sA, uint32_t la, uint32_t *s
 
 // Multiset intersection size.  ASCII: two 128-bin LDS histograms.  Otherwise rank counting: the
 // k-th occurrence (0-based) of a scalar value in a is matched iff k < its count in b.
+// Multiset intersection of two strings of scalar values with an open-addressing hash table (linear probing) of the
+// SHORTER string's values: entry = value << CB | count.  The other string then walks the table and every value that
+// finds a count left takes one unit (CAS), which is exactly sum_c min(countA[c], countB[c]).  E = u32 with CB = 11
+// (counts <= 1024: k_wave_pairs) or u64 with CB = 32 (any length: k_huge_pairs).  `size` (a power of two) entries at
+// `tab`; returns false if an insertion found the table full (the caller falls back to counting).
+template <class E, int CB>
+__device__ __forceinline__ bool wave_isect_hash(const uint32_t *S, uint32_t ns, const uint32_t *L, uint32_t nl, E *tab,
+                                                uint32_t bits, uint32_t &isect)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t size = 1u << bits, mask = size - 1u;
+    const E EMPTY = ~(E)0; // value field all ones: not a scalar value
+    for (uint32_t c = lane; c < size; c += 64u) tab[c] = EMPTY;
+    __syncthreads();
+    bool failed = false;
+    for (uint32_t i = lane; i < ns; i += 64u) {
+        const uint32_t sym = S[i];
+        uint32_t h = (sym * 2654435761u) >> (32u - bits);
+        uint32_t probe = 0;
+        for (; probe < size; ++probe, h = (h + 1u) & mask) {
+            E cur = *reinterpret_cast<volatile E *>(tab + h);
+            if (cur == EMPTY) cur = atomicCAS(tab + h, EMPTY, ((E)sym << CB) | (E)1);
+            if (cur == EMPTY) break;                                             // claimed the slot, count 1
+            if ((uint32_t)(cur >> CB) == sym) { atomicAdd(tab + h, (E)1); break; } // this value's slot
+        }
+        failed = failed || probe == size;
+    }
+    __syncthreads();
+    if (__ballot(failed) != 0ull) return false;
+    uint32_t acc = 0;
+    for (uint32_t j = lane; j < nl; j += 64u) {
+        const uint32_t sym = L[j];
+        uint32_t h = (sym * 2654435761u) >> (32u - bits);
+        for (uint32_t probe = 0; probe < size; ++probe, h = (h + 1u) & mask) {
+            E cur = *reinterpret_cast<volatile E *>(tab + h);
+            if (cur == EMPTY) break; // not in the shorter string
+            if ((uint32_t)(cur >> CB) != sym) continue;
+            while ((cur & (((E)1 << CB) - (E)1)) != (E)0) { // take one unit if any is left
+                const E old = atomicCAS(tab + h, cur, cur - (E)1);
+                if (old == cur) { ++acc; break; }
+                cur = old;
+            }
+            break;
+        }
+    }
+    isect = wave_sum(acc);
+    __syncthreads();
+    return true;
+}
+
+// auxwords = words available at hist (>= 256)
 __device__ __forceinline__ uint32_t wave_multiset_isect(const uint32_t *sA, uint32_t la, const uint32_t *sB, uint32_t lb,
-                                                        uint32_t *hist /* >= 256 words */, bool nonascii)
+                                                        uint32_t *hist, uint32_t auxwords, bool nonascii)
 {
     const uint32_t lane = lane_id();
     uint32_t acc = 0;
@@ -1159,6 +1210,26 @@ __device__ __forceinline__ uint32_t wave_multiset_isect(const uint32_t *sA, uint
             acc += x < y ? x : y;
         }
     } else {
+        const bool a_short = la <= lb;
+        const uint32_t *S = a_short ? sA : sB, *L = a_short ? sB : sA;
+        const uint32_t ns = a_short ? la : lb, nl = a_short ? lb : la;
+        uint32_t isect = 0;
+        bool ok;
+        // at least two entries per value of the shorter string (load <= 1/2), no more than fit: a small table is
+        // cleared faster
+        uint32_t want = 32u - (uint32_t)__builtin_clz(2u * ns - 1u);
+        want = want < 6u ? 6u : want;
+        if (ns <= 1024u) { // counts fit 11 bits: one word per entry
+            uint32_t bits = 31u - (uint32_t)__builtin_clz(auxwords);
+            bits = bits < want ? bits : want;
+            ok = wave_isect_hash<unsigned int, 11>(S, ns, L, nl, hist, bits, isect);
+        } else {
+            uint32_t bits = 31u - (uint32_t)__builtin_clz(auxwords >> 1);
+            bits = bits < want ? bits : want;
+            ok = wave_isect_hash<unsigned long long, 32>(S, ns, L, nl, reinterpret_cast<unsigned long long *>(hist), bits, isect);
+        }
+        if (ok) return isect;
+        // table full (more distinct values than entries): count, a chunk of `a` at a time
         for (uint32_t i0 = 0; i0 < la; i0 += 64u) {
             const uint32_t i = i0 + lane;
             const bool in = i < la;
@@ -1179,7 +1250,7 @@ __device__ __forceinline__ uint32_t wave_multiset_isect(const uint32_t *sA, uint
 template <int MEASURE>
 __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uint32_t a0, uint32_t la8, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t b0, uint32_t lb8, uint32_t totalB,
-                                           uint32_t *sA, uint32_t *sB, uint32_t *aux, uint32_t cap)
+                                           uint32_t *sA, uint32_t *sB, uint32_t *aux, uint32_t cap, uint32_t auxwords)
 {
     const uint32_t lane = lane_id();
     if (la8 == 0u && lb8 == 0u) return 1.0;
@@ -1206,7 +1277,7 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
         r = epilogue_jaro(m, t, la, lb);
         if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, prefix);
     } else {
-        const uint32_t isect = wave_multiset_isect(sA, la, sB, lb, aux, nonascii);
+        const uint32_t isect = wave_multiset_isect(sA, la, sB, lb, aux, auxwords, nonascii);
         r = MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
     }
     return r;
@@ -1227,7 +1298,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     __shared__ uint32_t sA_l[LEV ? 1 : WAVE_CAP];
     __shared__ uint32_t sB_l[LEV ? 1 : WAVE_CAP];
-    __shared__ uint32_t aux_l[LEV ? 1 : WAVE_CAP + 64];
+    __shared__ uint32_t aux_l[LEV ? 1 : 2 * WAVE_CAP + 64]; // Jaro flags / the hash table of the multiset intersection
     uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * LEV_WS_WORDS : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
@@ -1449,7 +1520,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     continue;
                   }
                 }
-                const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP);
+                const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP, LEV ? WAVE_CAP + 64 : 2 * WAVE_CAP + 64);
                 if (lane == 0u) out[row] = r;
               }
               if (todo != 0ull) { // rows are left that did not fit: run what has been collected
@@ -1545,7 +1616,7 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
             if constexpr (MEASURE == LEVENSHTEIN)
                 r = huge_levenshtein(valA + a0, a1 - a0, valB + b0, b1 - b0, sA, sB, aux, s_tab);
             else
-                r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap);
+                r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap, 4u * (cap + 64u));
             if (lane == 0u) out[row] = r;
         }
     }

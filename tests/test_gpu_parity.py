@@ -239,6 +239,26 @@ def test_very_long_levenshtein_stripes(S, ctx):
     assert_bit_exact(got, O.batch_strings("levenshtein", B, A, 8), B, A, "levenshtein")
 
 
+@pytest.mark.parametrize("measure", ["jaccard", "sorensen_dice"])
+def test_multiset_intersection_hash_many_distinct_values(S, ctx, measure):
+    """Non-ASCII multiset intersection (hash table of the shorter string's scalar values): few and many distinct values,
+    heavy repeats, astral values, both the LDS (<= 1024 bytes) and the workspace (longer) tables."""
+    import random
+    rng = random.Random(47)
+    cjk = "".join(chr(c) for c in range(0x4E00, 0x4E00 + 1500))
+    few = "\u0430\u0431\u0432"
+    astral = "".join(chr(c) for c in range(0x1F600, 0x1F640)) + "ab\u00e9"
+    A, B = [], []
+    for la, lb, alpha in [(300, 320, cjk), (341, 341, cjk), (200, 30, few), (500, 510, few), (120, 100, astral), (64, 256, astral),
+                          (1500, 1400, cjk), (3000, 2600, cjk), (2500, 40, few), (5000, 4000, few), (1200, 1300, astral)]:
+        a = "".join(rng.choice(alpha) for _ in range(la))
+        b = "".join(rng.choice(alpha) for _ in range(lb)) if rng.random() < 0.5 else gen.edit(rng, a, alpha, 9)[:max(lb, 1)]
+        A.append(a)
+        B.append(b)
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+
+
 def test_shape_mismatch(S, ctx):
     with pytest.raises(S.ShapeMismatch, match="Inputs must have the same length, or one of them must be a Utf8 literal."):
         gpu(S, ctx, "jaro", ["a", "b"], ["a", "b", "c"])
