@@ -1099,6 +1099,112 @@ __device__ __forceinline__ uint32_t wave_compact(uint32_t *s, const uint8_t *fla
 
 // Jaro matching on scalar values (strsim.rs:200-237): a is walked sequentially, the window of b is
 // scanned 64 positions at a time and the lowest hit wins (ballot + ctz).  Destroys sA/sB.
+// In-place compaction of the entries of s[0..len) whose bit is set in the bit array flagw[] (bit i of word i / 32).
+__device__ __forceinline__ uint32_t wave_compact_bits(uint32_t *s, const uint32_t *flagw, uint32_t len)
+{
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+        const uint32_t i = c0 + lane;
+        const bool f = i < len && ((flagw[i >> 5] >> (i & 31u)) & 1u) != 0u;
+        const uint32_t v = f ? s[i] : 0u;
+        const unsigned long long bal = __ballot(f);
+        __syncthreads();
+        if (f) s[base + (uint32_t)__popcll(bal & lanemask_lt(lane))] = v;
+        base += (uint32_t)__popcll(bal);
+        __syncthreads();
+    }
+    return base;
+}
+
+// Jaro matching of one pair per wave, bit-parallel across the lanes (strsim.rs:200-237): lane k keeps positions
+// 32k .. 32k+31 of b -- its flags, the two window masks and the bit-planes of its 32 scalar values -- in registers
+// (lb <= 2048, values <= 0xFFFF, NP > highest bit that varies in the pair).  The characters of a are walked in order;
+// a character is wave-uniform, so its plane bits are scalar (s_bfe) and the match mask costs one v_bitop3 per plane;
+// the window masks slide by one position per step with a one-lane DPP carry; the first unflagged equal position in
+// the window is the lowest set bit of the lowest lane with a candidate (ballot + s_ff1).  Flags of a are collected
+// 32 per scalar word.  Transpositions as in the reference: the flagged values of both sides, compacted, compared
+// in order.  aw: >= la / 32 + 64 + 64 words of scratch.
+template <int NP>
+__device__ __forceinline__ void wave_jaro_bits(uint32_t *sA, uint32_t la, uint32_t *sB, uint32_t lb, uint32_t *aw,
+                                               uint32_t &m_out, uint32_t &t_out)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t mx = la > lb ? la : lb;
+    const uint32_t half = mx >> 1;
+    const uint32_t bound = (half ? half : 1u) - 1u;
+    uint32_t *faw = aw;                          // flags of a, one bit per position
+    uint32_t *fbw = aw + ((la + 31u) >> 5) + 1u; // flags of b (64 words), written at the end
+    // planes of this lane's 32 values of b
+    uint32_t P[NP];
+    {
+        uint32_t w[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const uint32_t j = lane * 32u + (uint32_t)k;
+            w[k] = j < lb ? sB[j] : 0u;
+        }
+        build_planes_sym<NP>([&](int k) { return w[k] & 0xFFFFu; }, P);
+    }
+    const uint32_t base = lane * 32u;
+    const uint32_t lbmask = lb <= base ? 0u : low_ones(lb - base);   // positions of b in this block
+    uint32_t hw = bound + 1u < lb ? bound + 1u : lb;                // himask: ones at [0, min(i + bound, lb - 1)]
+    uint32_t himask = hw <= base ? 0u : low_ones(hw - base);
+    uint32_t lomask = 0u;                                           // ones below max(0, i - bound)
+    uint32_t fb = 0u;
+    const uint32_t first = lane == 0u ? 1u : 0u;
+    uint32_t m = 0, fa_acc = 0;
+    const uint32_t ni = la < lb + bound ? la : lb + bound; // `.take(b.len() + bound)` (:208)
+    uint32_t c_next = ni ? sA[0] : 0u;
+    for (uint32_t i = 0; i < ni; ++i) {
+        const uint32_t c = uniform(c_next);
+        c_next = sA[i + 1u < la ? i + 1u : i];
+        uint32_t Eq = lbmask;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) Eq = bitop3<0x90>(Eq, P[k], 0u - ((c >> k) & 1u)); // scalar plane bit
+        const uint32_t cand = bitop3<0x20>(Eq & himask, lomask | fb, 0xFFFFFFFFu);      // a & ~b
+        const unsigned long long bal = __ballot(cand != 0u);
+        if (bal != 0ull) {
+            const uint32_t wl = (uint32_t)__builtin_ctzll(bal);
+            if (lane == wl) fb |= cand & (0u - cand);
+            ++m;
+            fa_acc |= 1u << (i & 31u);
+        }
+        if ((i & 31u) == 31u) {
+            if (lane == 0u) faw[i >> 5] = fa_acc;
+            fa_acc = 0u;
+        }
+        // slide the window: both masks shift up by one position, ones enter at the bottom
+        {
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)himask, 0x138, 0xF, 0xF, true);
+            himask = (__builtin_amdgcn_alignbit(himask, prev, 31) | first) & lbmask;
+        }
+        if (i >= bound) {
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lomask, 0x138, 0xF, 0xF, true);
+            lomask = __builtin_amdgcn_alignbit(lomask, prev, 31) | first;
+        }
+    }
+    // flush the flags (the tail of a beyond ni is unflagged)
+    {
+        const uint32_t nw = (la + 31u) >> 5;
+        const uint32_t done = ni >> 5; // whole words already written
+        if (lane == 0u && (ni & 31u) != 0u) faw[done] = fa_acc;
+        const uint32_t from = done + ((ni & 31u) != 0u ? 1u : 0u);
+        for (uint32_t w = from + lane; w < nw; w += 64u) faw[w] = 0u;
+        fbw[lane] = fb;
+    }
+    __syncthreads();
+    wave_compact_bits(sA, faw, la);
+    wave_compact_bits(sB, fbw, lb);
+    uint32_t t = 0;
+    for (uint32_t k0 = 0; k0 < m; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        t += (uint32_t)__popcll(__ballot(k < m && sA[k] != sB[k]));
+    }
+    m_out = m;
+    t_out = t;
+}
+
 __device__ __forceinline__ void wave_jaro(uint32_t *sA, uint32_t la, uint32_t *sB, uint32_t lb, uint8_t *fa, uint8_t *fb,
                                           uint32_t &m_out, uint32_t &t_out)
 {
@@ -1272,8 +1378,25 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
             prefix = ne ? (uint32_t)__builtin_ctzll(ne) : lim;
         }
         uint32_t m, t;
-        uint8_t *fl = reinterpret_cast<uint8_t *>(aux);
-        wave_jaro(sA, la, sB, lb, fl, fl + cap, m, t);
+        // bits that vary over both strings decide how many planes the match masks need
+        uint32_t o = 0u, n_ = 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < la; i += 64u) { o |= sA[i]; n_ &= sA[i]; }
+        for (uint32_t i = lane; i < lb; i += 64u) { o |= sB[i]; n_ &= sB[i]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            o |= (uint32_t)__shfl_xor((int)o, d);
+            n_ &= (uint32_t)__shfl_xor((int)n_, d);
+        }
+        o = uniform(o);
+        const uint32_t vary = uniform(o ^ n_);
+        if (lb <= 2048u && o <= 0xFFFFu) {
+            if (vary >> 11) wave_jaro_bits<16>(sA, la, sB, lb, aux, m, t);
+            else if (vary >> 7) wave_jaro_bits<11>(sA, la, sB, lb, aux, m, t);
+            else wave_jaro_bits<7>(sA, la, sB, lb, aux, m, t);
+        } else {
+            uint8_t *fl = reinterpret_cast<uint8_t *>(aux);
+            wave_jaro(sA, la, sB, lb, fl, fl + cap, m, t);
+        }
         r = epilogue_jaro(m, t, la, lb);
         if (MEASURE == JARO_WINKLER) r = epilogue_jaro_winkler(r, prefix);
     } else {
@@ -1298,7 +1421,9 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     __shared__ uint32_t sA_l[LEV ? 1 : WAVE_CAP];
     __shared__ uint32_t sB_l[LEV ? 1 : WAVE_CAP];
-    __shared__ uint32_t aux_l[LEV ? 1 : 2 * WAVE_CAP + 64]; // Jaro flags / the hash table of the multiset intersection
+    // Jaro: flags; Jaccard / Dice: the hash table of the multiset intersection (two entries per value)
+    constexpr int AUXW = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? WAVE_CAP + 64 : 2 * WAVE_CAP + 64;
+    __shared__ uint32_t aux_l[LEV ? 1 : AUXW];
     uint32_t *const sA = LEV ? lev_ws + (uint64_t)blockIdx.x * LEV_WS_WORDS : sA_l;
     uint32_t *const sB = LEV ? sA + (WAVE_CAP + 64) : sB_l;
     uint32_t *const aux = LEV ? sB + (WAVE_CAP + 64) : aux_l;
@@ -1520,7 +1645,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     continue;
                   }
                 }
-                const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP, LEV ? WAVE_CAP + 64 : 2 * WAVE_CAP + 64);
+                const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP, LEV ? WAVE_CAP + 64 : AUXW);
                 if (lane == 0u) out[row] = r;
               }
               if (todo != 0ull) { // rows are left that did not fit: run what has been collected
@@ -1647,7 +1772,9 @@ static void launch_pair(const LaunchArgs &a)
     const uint64_t nchunks = (a.n + 63u) >> 6;
     const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
     const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
-    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev : (uint64_t)a.wave_grid;
+    // LDS per wave: Jaro 12.4 KB (12 waves per CU), Jaccard / Dice 16.4 KB (9); a.wave_grid is 8 per CU
+    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
+                        : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 2u : (uint64_t)a.wave_grid * 9u / 8u;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
@@ -1696,7 +1823,9 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
     uint32_t sps;
     unsigned g3;
     wide_geometry(a, sps, g3);
-    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev : (uint64_t)a.wave_grid;
+    // LDS per wave: Jaro 12.4 KB (12 waves per CU), Jaccard / Dice 16.4 KB (9); a.wave_grid is 8 per CU
+    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
+                        : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 2u : (uint64_t)a.wave_grid * 9u / 8u;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
     hipLaunchKernelGGL((k_lane_wide<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask, sps);
