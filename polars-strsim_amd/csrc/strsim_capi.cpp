@@ -4,6 +4,7 @@
 // (reference src/expressions/strsim.rs:41-107): shape rule, literal broadcast, row partition.
 // There is no CPU compute path in this library: without a HIP device every compute call fails.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdarg>
 #include <cstdio>
@@ -287,11 +288,11 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3;
-    la.wave_grid = c->num_cu * 8;
+    la.wave_grid = c->num_cu * 16;                       // k_wave_pairs, other measures: 4 waves per SIMD
     la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // 8 KB of LDS (match table) per wave
-    la.lev_ws = nullptr;
-    if (measure == STRSIM_LEVENSHTEIN || all) {
-        rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, (size_t)la.wave_grid_lev * LEV_WS_WORDS * sizeof(uint32_t));
+    {   // per-wave global scratch of k_wave_pairs (scalar-value arrays; Levenshtein: text arenas as well)
+        const size_t waves = (size_t)std::max(la.wave_grid, la.wave_grid_lev);
+        rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, waves * LEV_WS_WORDS * sizeof(uint32_t));
         if (rc) return rc;
         la.lev_ws = c->lev_ws;
     }
