@@ -139,6 +139,11 @@ STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms,
  * (valid after strsim_ctx_synchronize()). */
 STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
 
+/* Rows of the calls retired by the last strsim_ctx_synchronize() that held a string longer than
+ * STRSIM_WAVE_PATH_MAX_BYTES: their results were written by the second pass that synchronize runs, i.e. AFTER anything
+ * the caller enqueued on the stream behind the call (a caller that copies results out early re-copies when > 0). */
+STRSIM_API uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *ctx);
+
 /*
  * Lossless 16-bit transport codec for result columns (csrc/strsim_codec.hip).  A similarity of two strings of at
  * most `max_chars` characters takes few distinct values (max_chars = 32: 325 / 22 856 / 57 359 / 631 / 631 for the

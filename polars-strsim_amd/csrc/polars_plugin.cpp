@@ -554,15 +554,21 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
             if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1],
                                     static_cast<double *>(sl.d_out.p), sl.rows) != STRSIM_OK)
                 fail(strsim_last_error_message());
+            // results come back right behind the kernels (no separate round trip later)
+            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
         };
-        auto finish = [&](Slot &sl) {
+        auto wait = [&](Slot &sl) {
             tm.start();
             if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
             tm.stop(tm.t_wait);
-            tm.start();
-            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIP_OR_FAIL(hipStreamSynchronize(stream));
-            tm.stop(tm.t_d2h);
+            if (strsim_ctx_last_long_rows(ctx) != 0) { // rows finished by that pass: fetch the column again
+                tm.start();
+                HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIP_OR_FAIL(hipStreamSynchronize(stream));
+                tm.stop(tm.t_d2h);
+            }
+        };
+        auto copy_out = [&](Slot &sl) {
             tm.start();
             const double *src = static_cast<const double *>(sl.h_out.p);
             const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
@@ -573,6 +579,8 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
             tm.stop(tm.t_copy);
         };
 
+        // two slots: while the GPU works on slot `cur` (H2D, kernels, D2H) the host packs the next slice into the other
+        // slot, and it copies a finished slice out only after the next one has been launched
         uint64_t r0 = 0;
         int cur = 0;
         tm.start(); r0 += pack(g_ctx.slot[cur], r0, SLICE_ROWS); tm.stop(tm.t_pack);
@@ -580,11 +588,13 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         while (r0 < n) {
             const int nxt = cur ^ 1;
             tm.start(); r0 += pack(g_ctx.slot[nxt], r0, SLICE_ROWS); tm.stop(tm.t_pack); // overlaps the GPU work of slot `cur`
-            finish(g_ctx.slot[cur]);
+            wait(g_ctx.slot[cur]);
             tm.start(); launch(g_ctx.slot[nxt]); tm.stop(tm.t_launch);
+            copy_out(g_ctx.slot[cur]); // overlaps the GPU work of slot `nxt`
             cur = nxt;
         }
-        finish(g_ctx.slot[cur]);
+        wait(g_ctx.slot[cur]);
+        copy_out(g_ctx.slot[cur]);
     }
 
     // output validity = AND of the input validities (broadcast for a literal)

@@ -76,6 +76,7 @@ struct strsim_ctx {
     size_t huge_ws_cap = 0;
     int head = 0;
     uint64_t last_wave_rows = 0;
+    uint64_t last_long_rows = 0; // over the slots retired by the last synchronize
     // staging for strsim_pairs_host (grow-only device buffers)
     void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[5] = {0, 0, 0, 0, 0};
@@ -120,6 +121,7 @@ static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
 static int ctx_drain(strsim_ctx *c)
 {
     int rc = STRSIM_OK;
+    c->last_long_rows = 0;
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
@@ -134,6 +136,7 @@ static int ctx_drain(strsim_ctx *c)
         }
         const DevStatus &st = c->status_host[s];
         c->last_wave_rows = st.wave_rows;
+        c->last_long_rows += st.huge_rows;
         if (st.huge_rows != 0 && rc == STRSIM_OK) rc = ctx_run_huge(c, s, st);
     }
     return rc;
@@ -397,5 +400,6 @@ int strsim_ctx_timing_read(strsim_ctx_t *c, double *lane_ms, uint64_t *lane_laun
 }
 
 uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *c) { return c ? c->last_wave_rows : 0; }
+uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *c) { return c ? c->last_long_rows : 0; }
 
 } // extern "C"

@@ -82,6 +82,8 @@ def lib():
                                          C.POINTER(u64)]
     L.strsim_ctx_last_wave_rows.restype = u64
     L.strsim_ctx_last_wave_rows.argtypes = [vp]
+    L.strsim_ctx_last_long_rows.restype = u64
+    L.strsim_ctx_last_long_rows.argtypes = [vp]
     _lib = L
     return L
 

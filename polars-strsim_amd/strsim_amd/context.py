@@ -67,6 +67,11 @@ class Context:
     def last_wave_rows(self):
         return int(lib().strsim_ctx_last_wave_rows(self._h))
 
+    @property
+    def last_long_rows(self):
+        """Rows with a string beyond the wave-kernel cap among the calls the last synchronize() retired."""
+        return int(lib().strsim_ctx_last_long_rows(self._h))
+
     # ---- device-resident (torch tensors on this context's GPU) -------------------------------------
     def pairs_device(self, measure, a_offsets, a_values, b_offsets, b_values, out=None):
         """Enqueue one pass; tensors are torch CUDA tensors (offsets int32/uint32 [rows+1], values uint8).
