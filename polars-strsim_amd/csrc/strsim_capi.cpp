@@ -266,6 +266,10 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         return STRSIM_ERR_ARG;
     }
     if (n == 0) return STRSIM_OK;
+    if (n > 0xFFFFFFFFull) { // row and chunk indices are 32-bit inside the kernels (as are the offsets themselves)
+        set_error("strsim_pairs_device: %llu rows in one call; split the column (at most 2^32 - 1 rows per call)", (unsigned long long)n);
+        return STRSIM_ERR_ARG;
+    }
     if (!a_off || !b_off || !outs) { set_error("strsim_pairs_device: NULL buffer"); return STRSIM_ERR_ARG; }
     for (int q = 0; q < (all ? STRSIM_NUM_MEASURES : 1); ++q)
         if (!outs[q]) { set_error("strsim_pairs_device: NULL output buffer"); return STRSIM_ERR_ARG; }
