@@ -93,7 +93,7 @@ constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coale
 
 // COLS_PER_TEST * ceil(max over the wave of v / COLS_PER_TEST), at least COLS_PER_TEST (v <= 32): a binary search
 // with ballots, result in an SGPR
-__device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
+__device__ __forceinline__ uint32_t wave_max_rounded(uint32_t v)
 {
     constexpr uint32_t C = (uint32_t)COLS_PER_TEST;
     uint32_t g = 0; // groups of C columns below the answer
@@ -103,9 +103,6 @@ __device__ __forceinline__ uint32_t wave_max_round4(uint32_t v)
     return C * (g + 1u);
 }
 
-#ifndef STRSIM_LANE_PREFETCH
-#define STRSIM_LANE_PREFETCH 0
-#endif
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
 
 struct OutPtrs {
@@ -207,13 +204,12 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
         __syncthreads();
 
         // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
-        // the windows of a round are fetched while the round before it computes (a wave's two rounds, software-pipelined)
-        struct RoundIn { uint32_t idx, la8, lb8; bool fast; };
-        auto fetch_round = [&](int rr, RoundIn &in, uint32_t (&wa)[8], uint32_t (&wb)[8]) {
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
             const uint32_t r = rr ? (uint32_t)(LANE_ROUNDS - 1) - wv : wv;
             const uint32_t idx = s_perm[r * 64u + lane];
             const uint32_t len = s_len[idx];
-            const bool fast = len != 0xFFFFFFFFu;
+            bool fast = len != 0xFFFFFFFFu;
             uint32_t la8 = fast ? (len & 0xFFFFu) : 0u, lb8 = fast ? (len >> 16) : 0u;
             // symmetric measures walk the shorter string: pick the roles BEFORE loading (no register swap);
             // rows this kernel skips read a harmless window at offset 0
@@ -223,27 +219,10 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
             uint32_t t0 = swap ? s_b0[idx] : s_a0[idx], p0 = swap ? s_a0[idx] : s_b0[idx];
             if (!fast) { t0 = 0u; p0 = 0u; }
             if (swap) { const uint32_t t = la8; la8 = lb8; lb8 = t; }
+            // (fetching the second round's windows during the first round was tried: 102 VGPRs, 4 waves per SIMD, -11 %)
+            uint32_t wa[8], wb[8];
             load_window32(vT, t0, tT, wa);
             load_window32(vP, p0, tP, wb);
-            in = RoundIn{idx, la8, lb8, fast};
-        };
-        RoundIn cur;
-        uint32_t wa[8], wb[8];
-        fetch_round(0, cur, wa, wb);
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-            RoundIn nxt = cur;
-            uint32_t na[8], nb[8];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) { na[d] = 0u; nb[d] = 0u; }
-#if STRSIM_LANE_PREFETCH
-            if (rr == 0) fetch_round(1, nxt, na, nb);
-#else
-            if (rr == 1) fetch_round(1, cur, wa, wb);
-#endif
-            const uint32_t idx = cur.idx;
-            bool fast = cur.fast;
-            const uint32_t la8 = cur.la8, lb8 = cur.lb8;
             // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any
             // high bit sends the row to the code-point kernel; the varying low bits decide how many bit-planes
             // the match masks need
@@ -253,9 +232,9 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
                 fast = false;
                 atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
             }
-            if (__ballot(fast) != 0ull) {
+            if (__ballot(fast) == 0ull) continue;
             const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
-            const uint32_t tmax = wave_max_round4(la);
+            const uint32_t tmax = wave_max_rounded(la);
             const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
             const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
             if (MEASURE == ALL_MEASURES) {
@@ -275,10 +254,6 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
                 else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab);
                 if (fast) s_out[0][idx] = res;
             }
-            }
-            cur = nxt;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) { wa[d] = na[d]; wb[d] = nb[d]; }
         }
         __syncthreads();
         // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
