@@ -54,7 +54,7 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
-    int lane_wg_per_cu = 6; // STRSIM_LANE_WG_PER_CU overrides (tuning knob); 6 x 4 waves = 6 per SIMD
+    int lane_wg_per_cu = 64; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;
@@ -190,7 +190,7 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *env = getenv("STRSIM_LANE_WG_PER_CU")) {
         const int v = atoi(env);
-        if (v >= 1 && v <= 16) c->lane_wg_per_cu = v;
+        if (v >= 1 && v <= 4096) c->lane_wg_per_cu = v;
     }
     if (const char *env = getenv("STRSIM_LEV_WAVES_PER_CU")) {
         const int v = atoi(env);
@@ -294,7 +294,15 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
-    la.wide_grid = c->num_cu * 3;
+    la.wide_grid = c->num_cu * 3; // resident (LDS)
+    {
+        int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)
+        if (const char *env = getenv("STRSIM_WIDE_WG_PER_CU")) {
+            const int v = atoi(env);
+            if (v >= 1 && v <= 4096) wide_cap_per_cu = v;
+        }
+        la.wide_grid_cap = c->num_cu * wide_cap_per_cu;
+    }
     la.wave_grid = c->num_cu * 16;                       // k_wave_pairs, other measures: 4 waves per SIMD
     la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // 8 KB of LDS (match table) per wave
     {   // per-wave global scratch of k_wave_pairs (scalar-value arrays; Levenshtein: text arenas as well)

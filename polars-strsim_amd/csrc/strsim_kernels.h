@@ -48,6 +48,7 @@ struct LaunchArgs {
     DevStatus *status;            // zeroed by the caller
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
+    int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
     uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words
     hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)

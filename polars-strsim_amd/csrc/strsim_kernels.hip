@@ -122,12 +122,10 @@ struct OutPtrs {
 #endif
 
 template <int MEASURE>
-__global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const uint32_t *__restrict__ offA,
-                                                           const uint8_t *__restrict__ valA, uint64_t rowsA,
-                                                           const uint32_t *__restrict__ offB,
-                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
-                                                           OutPtrs outs, uint64_t n,
-                                                           unsigned long long *__restrict__ slowmask)
+__device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
+                                                uint64_t rowsA, const uint32_t *__restrict__ offB,
+                                                const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
+                                                unsigned long long *__restrict__ slowmask)
 {
     constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
     __shared__ uint32_t s_cnt[2][8];                    // bucket counters (double-buffered by block parity)
@@ -270,6 +268,27 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
                 slowmask[row >> 6] = sk & (n - row >= 64u ? ~0ull : ((1ull << (n - row)) - 1ull));
         }
     }
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const uint32_t *__restrict__ offA,
+                                                                          const uint8_t *__restrict__ valA, uint64_t rowsA,
+                                                                          const uint32_t *__restrict__ offB,
+                                                                          const uint8_t *__restrict__ valB, uint64_t rowsB,
+                                                                          OutPtrs outs, uint64_t n,
+                                                                          unsigned long long *__restrict__ slowmask)
+{
+    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask);
+}
+
+// The fused five-output instantiation needs more registers: asked for 5 waves per SIMD it fits 126 VGPRs = 4 waves
+// (132 = 3 waves when asked for 6, or for nothing).
+__global__ __launch_bounds__(LANE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
+k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
+                 const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
+                 unsigned long long *__restrict__ slowmask)
+{
+    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1731,7 +1750,9 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // k_lane_wide / k_lane_utf8 geometry: spans (32 mask words) per super-span and workgroups.  A super is what one
 // workgroup tests for "anything to do" with a single barrier; full-size frames use the largest (8 spans), smaller
-// ones shrink it until there are about two supers per resident workgroup.
+// ones shrink it until there are about two supers per RESIDENT workgroup (a.wide_grid = 3 per CU).  The launch
+// itself may be much larger than what is resident (a.wide_grid_cap): workgroups that finish early are replaced by
+// fresh ones instead of waiting for the longest grid-stride loop (cfg3: 12.4 -> 10.3 ms).
 static void wide_geometry(const LaunchArgs &a, uint32_t &sps, unsigned &grid)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
@@ -1742,7 +1763,7 @@ static void wide_geometry(const LaunchArgs &a, uint32_t &sps, unsigned &grid)
     if (k > (uint64_t)(WIDE_BLOCK / WIDE_SPAN)) k = WIDE_BLOCK / WIDE_SPAN;
     sps = (uint32_t)k;
     const uint64_t nsuper = (nspans + k - 1u) / k;
-    grid = (unsigned)(nsuper < (uint64_t)a.wide_grid ? nsuper : (uint64_t)a.wide_grid);
+    grid = (unsigned)(nsuper < (uint64_t)a.wide_grid_cap ? nsuper : (uint64_t)a.wide_grid_cap);
 }
 
 template <int M>
@@ -1825,7 +1846,7 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     OutPtrs op{};
     for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
-    hipLaunchKernelGGL((k_lane_pairs<ALL_MEASURES>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
+    hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
                        a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
