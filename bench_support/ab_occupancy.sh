@@ -1,5 +1,5 @@
 for round in 1 2; do
-for cfg in "0 5" "6 6" "6 7" "7 7" "8 8"; do
+for cfg in "0 64" "5 64" "6 64" "7 64" "8 64" "6 128"; do
   set -- $cfg
   make -C polars-strsim_amd -B EXTRA="-DSTRSIM_LANE_WAVES_PER_EU=$1" >/dev/null 2>&1
   for m in levenshtein jaro; do

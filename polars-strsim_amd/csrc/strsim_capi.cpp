@@ -54,7 +54,7 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
-    int lane_wg_per_cu = 64; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
+    int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
     unsigned long long *slowmask = nullptr;
