@@ -128,7 +128,12 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
                                                 unsigned long long *__restrict__ slowmask)
 {
     constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
-    __shared__ uint32_t s_cnt[2][8];                    // bucket counters (double-buffered by block parity)
+#ifndef STRSIM_LANE_BUCKET_SHIFT
+#define STRSIM_LANE_BUCKET_SHIFT 2
+#endif
+    constexpr int BSH = STRSIM_LANE_BUCKET_SHIFT;        // buckets of 2^BSH column counts (4; buckets of 2 measured 1 % slower)
+    constexpr int NBK = (32 >> BSH) + 1;                 // + one for the rows this kernel skips (sorted last)
+    __shared__ uint32_t s_cnt[2][NBK];                  // bucket counters (double-buffered by block parity)
     __shared__ unsigned long long s_late[2][LANE_ROUNDS]; // rows found non-ASCII after their bytes were loaded
     __shared__ uint16_t s_perm[LANE_ROWS];
     __shared__ uint32_t s_a0[LANE_ROWS];
@@ -159,7 +164,8 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
 
     for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, par ^= 1u) {
         const uint64_t row0 = blk * LANE_ROWS;
-        if (tid < 8u) { s_cnt[par][tid] = 0u; s_late[par][tid] = 0ull; }
+        if (tid < (uint32_t)NBK) s_cnt[par][tid] = 0u;
+        if (tid < 8u) s_late[par][tid] = 0ull;
         __syncthreads();
         // ---- phase 1 (coalesced): offsets -> lengths -> bucket + rank; stage offsets in LDS ---------
         uint32_t key[LANE_RPT], rank[LANE_RPT];
@@ -180,7 +186,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             skip[q] = __ballot(!mine);
             // bucket by the number of DP columns the pair will run (SYMMETRIC measures walk the shorter string)
             const uint32_t steps = SYMMETRIC ? (la8 < lb8 ? la8 : lb8) : la8;
-            key[q] = mine ? (((steps ? steps : 1u) - 1u) >> 2) : 7u;
+            key[q] = mine ? (((steps ? steps : 1u) - 1u) >> BSH) : (uint32_t)(NBK - 1);
             rank[q] = atomicAdd(&s_cnt[par][key[q]], 1u);
             s_a0[i] = a0;
             s_b0[i] = b0;
@@ -188,14 +194,14 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
         }
         __syncthreads();
         {
-            uint32_t c[8];
+            uint32_t c[NBK];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = s_cnt[par][k];
+            for (int k = 0; k < NBK; ++k) c[k] = s_cnt[par][k];
 #pragma unroll
             for (int q = 0; q < LANE_RPT; ++q) {
                 uint32_t base = 0;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) base += ((uint32_t)k < key[q]) ? c[k] : 0u;
+                for (int k = 0; k < NBK - 1; ++k) base += ((uint32_t)k < key[q]) ? c[k] : 0u;
                 s_perm[base + rank[q]] = (uint16_t)(q * LANE_BLOCK + tid);
             }
         }
