@@ -85,7 +85,10 @@ __device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, 
 // is touched by the same CU within a few microseconds: L1/L2 hits); results are staged in LDS and
 // stored coalesced.
 // ------------------------------------------------------------------------------------------------
-constexpr int LANE_BLOCK = 256;                  // threads per workgroup
+#ifndef STRSIM_LANE_BLOCK
+#define STRSIM_LANE_BLOCK 256
+#endif
+constexpr int LANE_BLOCK = STRSIM_LANE_BLOCK;    // threads per workgroup
 constexpr int LANE_WAVES = LANE_BLOCK / 64;      // 4
 constexpr int LANE_ROUNDS = 2 * LANE_WAVES;      // 8 rounds of 64 rows per block
 constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
@@ -165,7 +168,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
     for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, par ^= 1u) {
         const uint64_t row0 = blk * LANE_ROWS;
         if (tid < (uint32_t)NBK) s_cnt[par][tid] = 0u;
-        if (tid < 8u) s_late[par][tid] = 0ull;
+        if (tid < (uint32_t)LANE_ROUNDS) s_late[par][tid] = 0ull;
         __syncthreads();
         // ---- phase 1 (coalesced): offsets -> lengths -> bucket + rank; stage offsets in LDS ---------
         uint32_t key[LANE_RPT], rank[LANE_RPT];
