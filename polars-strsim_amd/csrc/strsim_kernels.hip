@@ -407,8 +407,16 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     done = fast;
 }
 
+// Register budget: on its own the compiler takes 157 (Levenshtein, Jaccard, Dice) to 199 (Jaro) VGPRs = 3 / 2 waves per
+// SIMD; asked for 3 it fits 168 and spills ~40 registers in the four-word Jaro path, and cfg3 still gains 11 %
+// (7.50 -> 8.34 G pairs/s).  Two kernels, one per width, so that the two-word rows run at 4 waves per SIMD were tried:
+// 8.13 G on cfg3 and -10 % on a 33-128-byte frame (a second scan + collect pass, half-empty rounds).
+#ifndef STRSIM_WIDE_WAVES_PER_EU
+#define STRSIM_WIDE_WAVES_PER_EU 3
+#endif
+
 template <int MEASURE>
-__global__ __launch_bounds__(WIDE_BLOCK) void k_lane_wide(const uint32_t *__restrict__ offA,
+__global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_WIDE_WAVES_PER_EU))) void k_lane_wide(const uint32_t *__restrict__ offA,
                                                           const uint8_t *__restrict__ valA, uint64_t rowsA,
                                                           const uint32_t *__restrict__ offB,
                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
