@@ -164,6 +164,16 @@ STRSIM_API int strsim_codec_encode(strsim_ctx_t *ctx, const strsim_codec_t *code
 /* codes[n] -> out[n]; rows coded 0xFFFF are left untouched. */
 STRSIM_API int strsim_codec_decode(strsim_ctx_t *ctx, const strsim_codec_t *codec, const uint16_t *codes, uint64_t n,
                                    double *out);
+/* Packed transport of the same codes: strsim_codec_bits() bits per row (the smallest b with 2^b > entries; the
+ * all-ones code is the escape), 64 / bits rows per 64-bit word: 9.14 bits per row for Levenshtein (325 values),
+ * 10.67 for Jaccard / Dice (631).  words[strsim_codec_packed_words(codec, n)]; exceptions as in strsim_codec_encode. */
+STRSIM_API uint32_t strsim_codec_bits(const strsim_codec_t *codec);
+STRSIM_API uint64_t strsim_codec_packed_words(const strsim_codec_t *codec, uint64_t n);
+STRSIM_API int strsim_codec_encode_packed(strsim_ctx_t *ctx, const strsim_codec_t *codec, const double *vals, uint64_t n,
+                                          uint64_t *words, uint32_t *exc_count, uint32_t *exc_rows, double *exc_vals,
+                                          uint32_t exc_cap);
+STRSIM_API int strsim_codec_decode_packed(strsim_ctx_t *ctx, const strsim_codec_t *codec, const uint64_t *words, uint64_t n,
+                                          double *out);
 /* out[row_base + exc_rows[i]] = exc_vals[i] for i < count. */
 STRSIM_API int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_rows,
                                   const double *exc_vals, uint32_t count);

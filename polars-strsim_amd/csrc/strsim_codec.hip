@@ -143,6 +143,54 @@ __global__ void k_decode(const uint16_t *__restrict__ codes, uint64_t n, double 
     }
 }
 
+// Packed transport: `bits` bits per code (2^bits > entries; the all-ones code is the escape), 64 / bits codes per
+// 64-bit word, one word per thread.  Rows past n code as 0.
+__global__ void k_encode_packed(const double *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ words,
+                                uint64_t nwords, uint32_t bits, const unsigned long long *__restrict__ keys,
+                                const uint16_t *__restrict__ kvals, uint32_t mask, uint32_t *__restrict__ exc_count,
+                                uint32_t *__restrict__ exc_rows, double *__restrict__ exc_vals, uint32_t exc_cap)
+{
+    const uint32_t per = 64u / bits;
+    const unsigned long long esc = (1ull << bits) - 1ull;
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long acc = 0ull;
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint64_t i = w * per + j;
+            if (i >= n) break;
+            const double v = vals[i];
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            uint32_t h = hash_bits(b) & mask;
+            unsigned long long code = esc;
+            for (;;) {
+                const unsigned long long k = keys[h];
+                if (k == b) { code = kvals[h]; break; }
+                if (k == EMPTY_KEY) break;
+                h = (h + 1u) & mask;
+            }
+            if (code == esc) {
+                const uint32_t slot = atomicAdd(exc_count, 1u);
+                if (slot < exc_cap) { exc_rows[slot] = (uint32_t)i; exc_vals[slot] = v; }
+            }
+            acc |= code << (j * bits);
+        }
+        words[w] = acc;
+    }
+}
+
+// one row per thread (coalesced stores; the `per` threads of a word share its load): row i sits in word i / per at
+// bit (i % per) * bits; `magic` = ceil(2^64 / per), exact for i < 2^32
+__global__ void k_decode_packed(const unsigned long long *__restrict__ words, uint64_t n, uint32_t per, uint32_t bits,
+                                unsigned long long magic, double *__restrict__ out, const double *__restrict__ table)
+{
+    const unsigned long long esc = (1ull << bits) - 1ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = __umul64hi(i, magic);
+        const uint32_t j = (uint32_t)(i - w * per);
+        const unsigned long long code = (words[w] >> (j * bits)) & esc;
+        if (code != esc) out[i] = table[code]; // escaped rows are left untouched (patched from the exception list)
+    }
+}
+
 __global__ void k_patch(double *__restrict__ out, const uint32_t *__restrict__ rows, const double *__restrict__ vals,
                         uint32_t count, uint64_t row_base)
 {
@@ -254,6 +302,51 @@ int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const 
     if (count == 0) return STRSIM_OK;
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
     hipLaunchKernelGGL(k_patch, dim3(grid_for(count)), dim3(256), 0, st, out, exc_rows, exc_vals, count, row_base);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+uint32_t strsim_codec_bits(const strsim_codec_t *c)
+{
+    if (!c) return 0;
+    uint32_t b = 1;
+    while ((1ull << b) <= (unsigned long long)c->entries) ++b; // 2^b > entries: the all-ones code stays free
+    return b;
+}
+
+uint64_t strsim_codec_packed_words(const strsim_codec_t *c, uint64_t n)
+{
+    if (!c) return 0;
+    const uint64_t per = 64u / strsim_codec_bits(c);
+    return (n + per - 1) / per;
+}
+
+int strsim_codec_encode_packed(strsim_ctx_t *ctx, const strsim_codec_t *c, const double *vals, uint64_t n, uint64_t *words,
+                               uint32_t *exc_count, uint32_t *exc_rows, double *exc_vals, uint32_t exc_cap)
+{
+    if (!ctx || !c || (!vals && n) || (!words && n) || !exc_count) { set_error("strsim_codec_encode_packed: NULL argument"); return STRSIM_ERR_ARG; }
+    if (n >> 32) { set_error("strsim_codec_encode_packed: more than 2^32 rows per call"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    HIP_TRY(hipMemsetAsync(exc_count, 0, sizeof(uint32_t), st));
+    if (n == 0) return STRSIM_OK;
+    const uint64_t nwords = strsim_codec_packed_words(c, n);
+    hipLaunchKernelGGL(k_encode_packed, dim3(grid_for(nwords)), dim3(256), 0, st, vals, n,
+                       reinterpret_cast<unsigned long long *>(words), nwords, strsim_codec_bits(c), c->d_keys, c->d_vals,
+                       c->hash_mask, exc_count, exc_rows, exc_vals, exc_cap);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_codec_decode_packed(strsim_ctx_t *ctx, const strsim_codec_t *c, const uint64_t *words, uint64_t n, double *out)
+{
+    if (!ctx || !c || (!words && n) || (!out && n)) { set_error("strsim_codec_decode_packed: NULL argument"); return STRSIM_ERR_ARG; }
+    if (n == 0) return STRSIM_OK;
+    if (reinterpret_cast<uintptr_t>(words) & 7u) { set_error("strsim_codec_decode_packed: words must be 8-byte aligned"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    const uint32_t bits = strsim_codec_bits(c), per = 64u / bits;
+    const unsigned long long magic = ~0ull / per + 1ull; // ceil(2^64 / per) for per that is not a power of two, exact else too
+    hipLaunchKernelGGL(k_decode_packed, dim3(grid_for(n)), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned long long *>(words), n, per, bits, magic, out, c->d_table);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

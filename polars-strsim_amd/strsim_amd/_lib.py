@@ -69,6 +69,14 @@ def lib():
     L.strsim_codec_encode.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32]
     L.strsim_codec_decode.restype = i32
     L.strsim_codec_decode.argtypes = [vp, vp, vp, u64, vp]
+    L.strsim_codec_bits.restype = C.c_uint32
+    L.strsim_codec_bits.argtypes = [vp]
+    L.strsim_codec_packed_words.restype = u64
+    L.strsim_codec_packed_words.argtypes = [vp, u64]
+    L.strsim_codec_encode_packed.restype = i32
+    L.strsim_codec_encode_packed.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32]
+    L.strsim_codec_decode_packed.restype = i32
+    L.strsim_codec_decode_packed.argtypes = [vp, vp, vp, u64, vp]
     L.strsim_codec_patch.restype = i32
     L.strsim_codec_patch.argtypes = [vp, vp, u64, vp, vp, C.c_uint32]
     L.strsim_ctx_synchronize.restype = i32

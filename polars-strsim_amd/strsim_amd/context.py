@@ -172,6 +172,33 @@ class Codec:
         check(lib().strsim_codec_decode(ctx._h, self._h, codes.data_ptr(), codes.numel(), out.data_ptr()))
         return out
 
+    @property
+    def bits(self):
+        """Bits per row of the packed transport (2^bits > entries; the all-ones code is the escape)."""
+        return int(lib().strsim_codec_bits(self._h))
+
+    def packed_words(self, n):
+        return int(lib().strsim_codec_packed_words(self._h, int(n)))
+
+    def encode_packed(self, vals, words=None, ctx=None):
+        """f64 tensor -> int64 tensor of packed_words(n) words, 64 // bits codes each; asynchronous on ctx's stream."""
+        import torch
+        ctx = ctx or self.ctx
+        if words is None:
+            words = torch.empty(self.packed_words(vals.numel()), dtype=torch.int64, device=vals.device)
+        check(lib().strsim_codec_encode_packed(ctx._h, self._h, vals.data_ptr(), vals.numel(), words.data_ptr(),
+                                               self.exc_count.data_ptr(), self.exc_rows.data_ptr(), self.exc_vals.data_ptr(),
+                                               self.EXC_CAP))
+        return words
+
+    def decode_packed(self, words, n, out=None, ctx=None):
+        import torch
+        ctx = ctx or self.ctx
+        if out is None:
+            out = torch.empty(int(n), dtype=torch.float64, device=words.device)
+        check(lib().strsim_codec_decode_packed(ctx._h, self._h, words.data_ptr(), int(n), out.data_ptr()))
+        return out
+
     def patch(self, out, row_base, exc_rows, exc_vals, count, ctx=None):
         ctx = ctx or self.ctx
         check(lib().strsim_codec_patch(ctx._h, out.data_ptr(), int(row_base), exc_rows.data_ptr(), exc_vals.data_ptr(),

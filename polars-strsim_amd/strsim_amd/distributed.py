@@ -90,14 +90,21 @@ class ShardGatherer:
         self.recv = torch.empty(n, dtype=torch.float64, device=device) if root else None
         self.recv_codes = None
         self.decoded = [None, None]
+        # bytes one rank ships per column: packed codes (64 // bits per 64-bit word) when that beats 16 bits per row
+        self.packed = bool(self.codecs) and all(64 // c.bits > 4 for c in self.codecs.values())
+        if self.codecs:
+            self.ship_bytes = max(8 * c.packed_words(rows) for c in self.codecs.values()) if self.packed else 2 * rows
         if self.codecs and root:  # codes travel as bytes: neither RCCL nor gloo has a 16-bit integer type
-            self.recv_codes = [torch.empty(2 * n, dtype=torch.uint8, device="cpu" if self.host else device) for _ in range(2)]
+            self.recv_codes = [torch.empty(self.world * self.ship_bytes, dtype=torch.uint8, device="cpu" if self.host else device)
+                               for _ in range(2)]
         elif root and self.host:
             self.recv_host = torch.empty(n, dtype=torch.float64)
 
     @property
     def transport(self):
-        return "u16 codes" if self.codecs else "f64"
+        if not self.codecs:
+            return "f64"
+        return "%d-bit codes, packed" % max(c.bits for c in self.codecs.values()) if self.packed else "u16 codes"
 
     def wait_slot(self, slot):
         """Call before overwriting the output buffer of `slot` (any hashable): its previous shipment must be done."""
@@ -113,24 +120,31 @@ class ShardGatherer:
             if codec is not None:
                 buf = self.codes.get(slot)
                 if buf is None:
-                    buf = self.codes[slot] = torch.empty(self.rows, dtype=torch.int16, device=self.dev)
+                    buf = self.codes[slot] = torch.empty(self.ship_bytes, dtype=torch.uint8, device=self.dev)
                 # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's
                 # VALU-bound kernels
-                src = codec.encode(out, buf, ctx=self.ctx_comm)
-            if codec is not None:
-                raw = src.view(torch.uint8)
+                if self.packed:
+                    codec.encode_packed(out, buf.view(torch.int64), ctx=self.ctx_comm)
+                else:
+                    codec.encode(out, buf.view(torch.int16), ctx=self.ctx_comm)
+                raw = buf
                 b = self.nsub & 1
                 self.nsub += 1
                 if self.rank == 0 and self.decoded[b] is not None:
                     self.comm.wait_event(self.decoded[b])  # the decode that last read this receive buffer
-                work, _ = gather_column(raw.cpu() if self.host else raw, 2 * self.world * self.rows, dst=0, async_op=True,
+                work, _ = gather_column(raw.cpu() if self.host else raw, self.world * self.ship_bytes, dst=0, async_op=True,
                                         recv_buffer=self.recv_codes[b] if self.rank == 0 else None)
                 work.wait()
                 if self.rank == 0:
                     self.decode.wait_stream(self.comm)
                     with torch.cuda.stream(self.decode):
                         rc = self.recv_codes[b].to(self.dev) if self.host else self.recv_codes[b]
-                        codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_decode)
+                        if self.packed:  # every rank packed its own shard: decode them one by one
+                            for r in range(self.world):
+                                seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes].view(torch.int64)
+                                codec.decode_packed(seg, self.rows, self.recv[r * self.rows:(r + 1) * self.rows], ctx=self.ctx_decode)
+                        else:
+                            codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_decode)
                         self.decoded[b] = torch.cuda.Event()
                         self.decoded[b].record(self.decode)
             else:

@@ -1,5 +1,5 @@
 """Two ranks on ONE GPU (gloo, host-staged collectives) exercise bench.py's N > 1 control flow end to end: shard
-generation, kernels, side-stream shipping of every step's result shard (raw f64 and 16-bit codec transport, single
+generation, kernels, side-stream shipping of every step's result shard (raw f64, 16-bit and bit-packed codec transport, single
 measure and the fused five-measure pass) and the root-side decode -- rank 0 verifies what it gathered against every
 rank's checksum.  RCCL itself needs one GPU per rank and is only exercised by the driver's multi-GPU run."""
 import json
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("extra,transport", [([], "u16 codes"), (["--no-codec"], "f64"), (["--config", "cfg4"], "u16 codes")])
+@pytest.mark.parametrize("extra,transport", [([], "9-bit codes, packed"), (["--no-codec"], "f64"), (["--config", "cfg4"], "u16 codes"), (["--measure", "jaccard"], "10-bit codes, packed")])
 def test_two_ranks_ship_and_verify(extra, transport):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",

@@ -322,6 +322,7 @@ def test_transport_codec_round_trip(S, measure):
         assert 300 < codec.entries < 65535
         codes = codec.encode(vals)
         out = torch.full_like(vals, -1.0)
+        torch.cuda.synchronize()  # the context runs on its own stream (torch's default stream has handle 0)
         codec.decode(codes, out)
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -336,6 +337,24 @@ def test_transport_codec_round_trip(S, measure):
         assert torch.equal(out.view(torch.int64), vals.view(torch.int64))
         exp = O.batch_strings(measure, A, B, 8)
         assert_bit_exact(out.cpu().numpy(), exp, A, B, "codec " + measure)
+        # the packed transport of the same codes: bits per row by the table size, same exceptions, same round trip
+        bits = codec.bits
+        assert (1 << bits) > codec.entries >= (1 << (bits - 1))
+        for n_rows in (len(A), 50000, 7, 1):
+            v = vals[:n_rows]
+            words = codec.encode_packed(v)
+            assert words.numel() == -(-n_rows // (64 // bits))
+            out2 = torch.full_like(v, -1.0)
+            torch.cuda.synchronize()  # the context runs on its own stream (torch's default stream has handle 0)
+            codec.decode_packed(words, n_rows, out2)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            nexc2 = int(codec.exc_count.item())
+            assert int((out2 == -1.0).sum().item()) == nexc2
+            codec.patch(out2, 0, codec.exc_rows, codec.exc_vals, nexc2)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(out2.view(torch.int64), v.view(torch.int64))
         codec.close()
 
 
