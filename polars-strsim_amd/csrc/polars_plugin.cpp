@@ -151,19 +151,27 @@ void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64
         const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)a->length) - k.row0);
         if (c.layout == L_VIEW) {
             const View *v = static_cast<const View *>(a->buffers[1]) + a->offset;
+            // Arrow C data interface, Utf8View: the last buffer holds the int64 lengths of the variadic data buffers
+            const int64_t *sizes = a->n_buffers >= 4 ? static_cast<const int64_t *>(a->buffers[a->n_buffers - 1]) : nullptr;
+            const int64_t nvar = sizes ? a->n_buffers - 3 : a->n_buffers - 2; // variadic data buffers
             for (int64_t i = i0; i < i1; ++i) {
                 if (!k.nulls || bit_at(k.nulls, a->offset + i)) {
                     const uint32_t len = v[i].len;
-                    if (len <= 12) {
-                        if (pos + 12 <= limit) memcpy(val + pos, v[i].rest, 12); // fixed-size copy, trimmed by the next row
-                        else memcpy(val + pos, v[i].rest, len);
-                    } else {
-                        uint32_t bi, bo;
-                        memcpy(&bi, v[i].rest + 4, 4);
-                        memcpy(&bo, v[i].rest + 8, 4);
-                        if ((int64_t)bi + 2 >= a->n_buffers) fail("Utf8View buffer index out of range");
-                        memcpy(val + pos, static_cast<const uint8_t *>(a->buffers[2 + bi]) + bo, len);
-                    }
+                    // Whether a string sits in its view or in a data buffer is a coin flip per row (cfg2: 37 % / 63 %), so the
+                    // source pointer is SELECTED, not branched on, and the common case is one fixed 32-byte copy trimmed by
+                    // the next row: 32 bytes must be writable, and readable behind the source -- inside the views buffer
+                    // (two more views follow) or inside the data buffer (its length is in the trailing sizes buffer).
+                    const bool inl = len <= 12;
+                    uint32_t bi, bo;
+                    memcpy(&bi, v[i].rest + 4, 4);
+                    memcpy(&bo, v[i].rest + 8, 4);
+                    if (!inl && (int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+                    const uint32_t bsel = inl ? 0u : bi;
+                    const uint8_t *data = nvar > 0 ? static_cast<const uint8_t *>(a->buffers[2 + bsel]) : nullptr;
+                    const uint8_t *src = inl ? v[i].rest : data + bo;
+                    const bool room = inl ? i + 2 < a->length : (sizes != nullptr && (int64_t)bo + 32 <= sizes[bsel]);
+                    if (len <= 32 && room && pos + 32 <= limit) memcpy(val + pos, src, 32);
+                    else memcpy(val + pos, src, len);
                     pos += len;
                 }
                 *o_out++ = (uint32_t)pos;
