@@ -285,7 +285,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     // mask + backup (five-measure call) + the work list of k_lane_utf8 (one u32 per chunk)
     rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long) + nchunks * sizeof(uint32_t));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->status + slot, 0, sizeof(DevStatus), c->stream));
+    // (the status block of the slot is cleared by the first kernel of the call, k_lane_pairs)
 
     LaunchArgs la;
     la.offA = a_off; la.valA = a_val; la.rowsA = a_rows;

@@ -45,7 +45,7 @@ struct LaunchArgs {
     double *out; uint64_t n;
     unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
     uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
-    DevStatus *status;            // zeroed by the caller
+    DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)

@@ -128,7 +128,7 @@ template <int MEASURE>
 __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
                                                 uint64_t rowsA, const uint32_t *__restrict__ offB,
                                                 const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                                                unsigned long long *__restrict__ slowmask)
+                                                unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status)
 {
     constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
 #ifndef STRSIM_LANE_BUCKET_SHIFT
@@ -151,6 +151,8 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wv = tid >> 6;
+    // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
+    if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
     if (HAS_LEV) {
         // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: same IEEE division as the
         // epilogue, done once per workgroup instead of once per pair
@@ -285,9 +287,10 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
                                                                           const uint32_t *__restrict__ offB,
                                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                                           OutPtrs outs, uint64_t n,
-                                                                          unsigned long long *__restrict__ slowmask)
+                                                                          unsigned long long *__restrict__ slowmask,
+                                                                          DevStatus *__restrict__ status)
 {
-    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask);
+    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status);
 }
 
 // The fused five-output instantiation needs more registers: asked for 5 waves per SIMD it fits 126 VGPRs = 4 waves
@@ -295,9 +298,9 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
 __global__ __launch_bounds__(LANE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
 k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                 unsigned long long *__restrict__ slowmask)
+                 unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status)
 {
-    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask);
+    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1797,7 +1800,7 @@ static void launch_pair(const LaunchArgs &a)
     OutPtrs op{};
     op.p[0] = a.out;
     hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, op, a.n, a.slowmask);
+                       a.valB, a.rowsB, op, a.n, a.slowmask, a.status);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
         uint32_t sps;
@@ -1864,7 +1867,7 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
-                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask);
+                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
     if (e != hipSuccess) return e;
