@@ -90,12 +90,22 @@ static int ctx_set_device(strsim_ctx *c) { HIP_TRY(hipSetDevice(c->device)); ret
 
 static int ctx_reserve(void **p, size_t *cap, size_t bytes);
 
+static int huge_waves_per_cu()
+{
+    int v = 16; // STRSIM_HUGE_WAVES_PER_CU overrides (tuning knob); 8 KB of LDS per Levenshtein wave
+    if (const char *env = getenv("STRSIM_HUGE_WAVES_PER_CU")) {
+        const int e = atoi(env);
+        if (e >= 1 && e <= 32) v = e;
+    }
+    return v;
+}
+
 // Rows with a string longer than STRSIM_WAVE_PATH_MAX_BYTES: rerun them with the scratch arrays in global memory.
 static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
 {
     const uint32_t cap = (st.max_len + 63u) & ~63u;
     const size_t per_wave = (size_t)HUGE_WS_WORDS(cap) * sizeof(uint32_t);
-    const size_t max_waves = (size_t)c->num_cu * 8u; // two waves per SIMD
+    const size_t max_waves = (size_t)c->num_cu * (size_t)huge_waves_per_cu();
     size_t waves = st.huge_rows < max_waves ? st.huge_rows : max_waves;
     const size_t budget = (size_t)4 << 30; // keep the workspace under 4 GiB
     if (waves * per_wave > budget) waves = budget / per_wave ? budget / per_wave : 1;
