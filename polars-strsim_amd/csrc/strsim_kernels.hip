@@ -716,6 +716,29 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 __device__ __forceinline__ unsigned long long lanemask_lt(uint32_t lane) { return (1ull << lane) - 1ull; }
 
+// number of scalar values of a valid UTF-8 string = its bytes that are not continuation bytes
+__device__ __forceinline__ uint32_t wave_count_chars(const uint8_t *__restrict__ p, uint32_t len8)
+{
+    const uint32_t lane = lane_id();
+    uint32_t cnt = 0;
+    for (uint32_t c0 = 0; c0 < len8; c0 += 64u) {
+        const uint32_t i = c0 + lane;
+        cnt += (uint32_t)__popcll(__ballot(i < len8 && (p[i] & 0xC0u) != 0x80u));
+    }
+    return cnt;
+}
+
+// Levenshtein: a row with a string beyond WAVE_CAP BYTES still runs in k_wave_pairs' SYMBOLS batches when both strings
+// have at most WAVE_CAP scalar values (e.g. 600 Cyrillic letters = 1 200 bytes); k_huge_pairs applies the same test
+// and leaves such rows alone.
+constexpr uint32_t LEV_SYMBOL_ROUTE_MAX_BYTES = 4u * WAVE_CAP;
+__device__ __forceinline__ bool lev_fits_symbols(const uint8_t *__restrict__ pa, uint32_t la8, const uint8_t *__restrict__ pb,
+                                                 uint32_t lb8)
+{
+    if (la8 > LEV_SYMBOL_ROUTE_MAX_BYTES || lb8 > LEV_SYMBOL_ROUTE_MAX_BYTES) return false;
+    return wave_count_chars(pa, la8) <= (uint32_t)WAVE_CAP && wave_count_chars(pb, lb8) <= (uint32_t)WAVE_CAP;
+}
+
 // `str::chars()` across a wave: lane i looks at byte i, lead bytes decode their scalar value and
 // compact it to dst[rank].  Valid UTF-8 only (the Rust &str / Arrow Utf8 contract).
 __device__ __forceinline__ uint32_t wave_decode(const uint8_t *__restrict__ p, uint32_t len8, uint32_t *dst,
@@ -1575,7 +1598,8 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                 const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
                 const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
                 ++my_rows;
-                if (la8 > (uint32_t)WAVE_CAP || lb8 > (uint32_t)WAVE_CAP) {
+                bool long_bytes = la8 > (uint32_t)WAVE_CAP || lb8 > (uint32_t)WAVE_CAP;
+                if (long_bytes && !(LEV && la8 != 0u && lb8 != 0u && lev_fits_symbols(valA + a0, la8, valB + b0, lb8))) {
                     ++my_huge; // finished by k_huge_pairs, launched from strsim_ctx_synchronize()
                     const uint32_t ml = la8 > lb8 ? la8 : lb8;
                     my_maxlen = my_maxlen > ml ? my_maxlen : ml;
@@ -1588,7 +1612,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
                     const uint32_t Bn = (ms + 31u) >> 5;
                     uint32_t o6 = job_or6, n6 = job_and6;
-                    bool ascii = wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
+                    bool ascii = !long_bytes && wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
                     if (ascii) {
                         const uint32_t slot = (2u * TXT_PAD + nl + 3u) & ~3u;
                         if (bq0.njobs == (uint32_t)LEV_JOBS || bq0.lanes + Bn > 64u || bq0.used + slot > (uint32_t)ARENA0_BYTES) {
@@ -1756,8 +1780,10 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
             const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
             const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
             double r;
-            if constexpr (MEASURE == LEVENSHTEIN)
+            if constexpr (MEASURE == LEVENSHTEIN) {
+                if (a1 != a0 && b1 != b0 && lev_fits_symbols(valA + a0, a1 - a0, valB + b0, b1 - b0)) continue; // k_wave_pairs did it
                 r = huge_levenshtein(valA + a0, a1 - a0, valB + b0, b1 - b0, sA, sB, aux, s_tab);
+            }
             else
                 r = wave_row<MEASURE>(valA, a0, a1 - a0, totalA, valB, b0, b1 - b0, totalB, sA, sB, aux, cap, 4u * (cap + 64u));
             if (lane == 0u) out[row] = r;
