@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the HIP path against the CPU oracle: random scripts x length classes x measures x literal sides.
-Usage: python bench_support/fuzz.py [seconds] [seed].  Exits non-zero on the first mismatch (prints the row)."""
+Usage: python tests/fuzz_gpu.py [seconds] [seed].  Exits non-zero on the first mismatch (prints the row)."""
 import os
 import random
 import sys
@@ -8,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "polars-strsim_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # the oracle is test infrastructure: this script lives in tests/
 import numpy as np
 
 import gen
