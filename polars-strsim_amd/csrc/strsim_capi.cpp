@@ -75,6 +75,7 @@ struct strsim_ctx {
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
     int head = 0;
+    double *qtab = nullptr;          // QTAB_N x QTAB_N quotients a / b (strsim_lane_core.h), filled at creation
     uint64_t last_wave_rows = 0;
     uint64_t last_long_rows = 0; // over the slots retired by the last synchronize
     // staging for strsim_pairs_host (grow-only device buffers)
@@ -218,6 +219,14 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         e = hipHostMalloc((void **)&c->status_host, sizeof(DevStatus) * strsim_ctx::RING, hipHostMallocDefault);
     if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "status allocation"); }
     memset(c->status_host, 0, sizeof(DevStatus) * strsim_ctx::RING);
+    {   // integer quotients for the epilogues of k_lane_pairs: the host's IEEE division is the device's
+        static double q[QTAB_N * QTAB_N];
+        for (int a = 0; a < QTAB_N; ++a)
+            for (int b = 0; b < QTAB_N; ++b) q[a * QTAB_N + b] = b ? (double)a / (double)b : 0.0;
+        e = hipMalloc((void **)&c->qtab, sizeof(q));
+        if (e == hipSuccess) e = hipMemcpy(c->qtab, q, sizeof(q), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "quotient table"); }
+    }
     *out_ctx = c;
     return STRSIM_OK;
 }
@@ -232,6 +241,7 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
             if (c->ev[s][i]) (void)hipEventDestroy(c->ev[s][i]);
     for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
     if (c->slowmask) (void)hipFree(c->slowmask);
+    if (c->qtab) (void)hipFree(c->qtab);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
     if (c->lev_ws) (void)hipFree(c->lev_ws);
     if (c->status) (void)hipFree(c->status);
@@ -303,6 +313,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.out = outs[0]; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
+    la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.wide_grid = c->num_cu * 3; // resident (LDS)
     {

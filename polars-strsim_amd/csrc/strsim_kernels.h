@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "strsim_lane_core.h" // QTAB_N
+
 namespace strsim {
 
 constexpr int WAVE_CAP = 1024; // wave-per-pair kernels: max bytes (hence scalar values) per string
@@ -45,6 +47,7 @@ struct LaunchArgs {
     double *out; uint64_t n;
     unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
     uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
+    const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of k_lane_pairs (device)
     DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels

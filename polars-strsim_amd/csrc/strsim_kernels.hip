@@ -128,7 +128,8 @@ template <int MEASURE>
 __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
                                                 uint64_t rowsA, const uint32_t *__restrict__ offB,
                                                 const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                                                unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status)
+                                                unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
+                                                const double *__restrict__ qtab)
 {
     constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
 #ifndef STRSIM_LANE_BUCKET_SHIFT
@@ -248,9 +249,9 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
             if (MEASURE == ALL_MEASURES) {
                 double res[5];
-                if (need7) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res);
-                else if (need6) lane_all_results<6>(wa, la, wb, lb, tmax, s_levtab, res);
-                else lane_all_results<5>(wa, la, wb, lb, tmax, s_levtab, res);
+                if (need7) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
+                else if (need6) lane_all_results<6>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
+                else lane_all_results<5>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
                 if (fast) {
 #pragma unroll
                     for (int q = 0; q < NOUT; ++q) s_out[q][idx] = res[q];
@@ -258,9 +259,9 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             } else {
                 constexpr int M1 = MEASURE == ALL_MEASURES ? 0 : MEASURE;
                 double res;
-                if (need7) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab);
-                else if (need6) res = lane_pair_result<M1, 6>(wa, la, wb, lb, tmax, s_levtab);
-                else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab);
+                if (need7) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab, qtab);
+                else if (need6) res = lane_pair_result<M1, 6>(wa, la, wb, lb, tmax, s_levtab, qtab);
+                else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab, qtab);
                 if (fast) s_out[0][idx] = res;
             }
         }
@@ -288,9 +289,10 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
                                                                           const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                                           OutPtrs outs, uint64_t n,
                                                                           unsigned long long *__restrict__ slowmask,
-                                                                          DevStatus *__restrict__ status)
+                                                                          DevStatus *__restrict__ status,
+                                                                          const double *__restrict__ qtab)
 {
-    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status);
+    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
 }
 
 // The fused five-output instantiation needs more registers: asked for 5 waves per SIMD it fits 126 VGPRs = 4 waves
@@ -298,9 +300,9 @@ __global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const 
 __global__ __launch_bounds__(LANE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
 k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                 unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status)
+                 unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab)
 {
-    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status);
+    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1826,7 +1828,7 @@ static void launch_pair(const LaunchArgs &a)
     OutPtrs op{};
     op.p[0] = a.out;
     hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, op, a.n, a.slowmask, a.status);
+                       a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
         uint32_t sps;
@@ -1893,7 +1895,7 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
-                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status);
+                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
     if (e != hipSuccess) return e;
