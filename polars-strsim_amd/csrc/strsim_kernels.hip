@@ -90,7 +90,11 @@ __device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, 
 #endif
 constexpr int LANE_BLOCK = STRSIM_LANE_BLOCK;    // threads per workgroup
 constexpr int LANE_WAVES = LANE_BLOCK / 64;      // 4
-constexpr int LANE_ROUNDS = 2 * LANE_WAVES;      // 8 rounds of 64 rows per block
+#ifndef STRSIM_LANE_RPW
+#define STRSIM_LANE_RPW 2
+#endif
+constexpr int LANE_RPW = STRSIM_LANE_RPW;        // rounds per wave and block (even; 4 = 1 024-row blocks: measured no gain)
+constexpr int LANE_ROUNDS = LANE_RPW * LANE_WAVES; // rounds of 64 rows per block (8)
 constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
 constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coalesced phases (2)
 
@@ -112,11 +116,12 @@ struct OutPtrs {
     double *p[5]; // indexed by Measure; single-measure kernels use p[0]
 };
 
-// Register budget of k_lane_pairs: left alone the compiler takes 86 (Levenshtein) to 114 (Jaro) VGPRs = 5 / 4 waves
-// per SIMD; asked for 6 it fits 80 with 1-4 spilled registers outside the column loops (cfg2 on one box: Levenshtein
-// 2.30 -> 2.26 ms, Jaro 3.46 -> 3.21 ms; 7 and 8 waves lose again).  Goes with 6 workgroups per CU (strsim_capi.cpp).
+// Register budget of k_lane_pairs.  With five-, six- and seven-plane instantiations in one kernel the allocation was 86
+// (Levenshtein) to 114 (Jaro) VGPRs although each instantiation alone needs 52-57; dropping the six-plane one (it
+// runs as seven) brings the kernel to 63-64 VGPRs = 8 waves per SIMD with at most 9 spilled dwords: cfg2 Levenshtein
+// 2.02 -> 1.95 ms, Jaro 2.77 -> 2.69, Jaccard 1.78 -> 1.76 (6, 7 and 8 waves asked for measure the same).
 #ifndef STRSIM_LANE_WAVES_PER_EU
-#define STRSIM_LANE_WAVES_PER_EU 6
+#define STRSIM_LANE_WAVES_PER_EU 8
 #endif
 #if STRSIM_LANE_WAVES_PER_EU
 #define LANE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(STRSIM_LANE_WAVES_PER_EU)))
@@ -145,7 +150,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
     __shared__ uint32_t s_len[LANE_ROWS];               // la | lb << 16, or ~0 for rows this kernel skips
     __shared__ double s_out[NOUT][LANE_ROWS];
     constexpr bool HAS_LEV = MEASURE == LEVENSHTEIN || MEASURE == ALL_MEASURES;
-    __shared__ double s_levtab[HAS_LEV ? 33 * 33 : 1];
+    __shared__ double s_levtab[HAS_LEV ? 33 * 33 : 1]; // (in global memory instead, like qtab: measured 2-4 % slower)
 
     // Levenshtein distance and the multiset intersection do not depend on the argument order
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
@@ -215,8 +220,10 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
 
         // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
 #pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint32_t r = rr ? (uint32_t)(LANE_ROUNDS - 1) - wv : wv;
+        for (int rr = 0; rr < LANE_RPW; ++rr) {
+            // rounds come sorted by length: a wave takes one from each end of every group of 2 * LANE_WAVES rounds
+            const uint32_t grp = (uint32_t)(rr >> 1) * (2u * LANE_WAVES);
+            const uint32_t r = grp + ((rr & 1) ? (uint32_t)(2 * LANE_WAVES - 1) - wv : wv);
             const uint32_t idx = s_perm[r * 64u + lane];
             const uint32_t len = s_len[idx];
             bool fast = len != 0xFFFFFFFFu;
@@ -249,8 +256,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
             if (MEASURE == ALL_MEASURES) {
                 double res[5];
-                if (need7) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
-                else if (need6) lane_all_results<6>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
+                if (need7 || need6) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
                 else lane_all_results<5>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
                 if (fast) {
 #pragma unroll
@@ -259,8 +265,9 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             } else {
                 constexpr int M1 = MEASURE == ALL_MEASURES ? 0 : MEASURE;
                 double res;
-                if (need7) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab, qtab);
-                else if (need6) res = lane_pair_result<M1, 6>(wa, la, wb, lb, tmax, s_levtab, qtab);
+// Two instantiations, not three: with a six-plane variant beside these the register allocation of the whole
+                // kernel grew from 64 to 80+ VGPRs (each variant alone needs 52-57), i.e. from 8 to 6 waves per SIMD
+                if (need7 || need6) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab, qtab);
                 else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab, qtab);
                 if (fast) s_out[0][idx] = res;
             }
