@@ -413,8 +413,8 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const LdsTxt txt{txt_col};
     const LdsFaStore fst{fa_col};
     const LdsFaLoad fld{fa_col};
-    if (need7) res = lane_wide_result<MEASURE, 7, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
-    else if (need6) res = lane_wide_result<MEASURE, 6, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    // two instantiations per width (a six-plane one only inflated the kernel's register allocation, cf. k_lane_pairs)
+    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
     else res = lane_wide_result<MEASURE, 5, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
     done = fast;
 }
