@@ -212,6 +212,14 @@ def test_strings_beyond_the_wave_kernel_cap(S, ctx, measure):
     B.append(A[-1])
     got = gpu(S, ctx, measure, A, B)
     assert_bit_exact(got, O.batch_strings(measure, A, B, 8), A, B, measure)
+    # the second pass ran for exactly the rows with a string beyond the cap (for Levenshtein: beyond 1 024 scalar values too)
+    blen = lambda x: len(x.encode("utf-8"))
+    if measure == "levenshtein":  # byte lengths beyond the cap, unless both sides are non-empty and fit in scalar values
+        n_long = sum(1 for a, b in zip(A, B) if max(blen(a), blen(b)) > 1024 and
+                     not (a and b and max(blen(a), blen(b)) <= 4096 and max(len(a), len(b)) <= 1024))
+    else:
+        n_long = sum(1 for a, b in zip(A, B) if max(blen(a), blen(b)) > 1024)
+    assert ctx.last_long_rows == n_long, (ctx.last_long_rows, n_long)
     # and the context keeps working afterwards
     got = gpu(S, ctx, measure, A[:50], B[:50])
     assert_bit_exact(got, O.batch_strings(measure, A[:50], B[:50]), A[:50], B[:50], measure)
