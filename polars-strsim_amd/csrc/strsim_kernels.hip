@@ -420,8 +420,10 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const LdsFaStore fst{fa_col};
     const LdsFaLoad fld{fa_col};
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation, cf. k_lane_pairs)
+    __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
     if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
     else res = lane_wide_result<MEASURE, 5, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    __builtin_amdgcn_s_setprio(1);
     done = fast;
 }
 
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int RPT = WIDE_ROWS / WIDE_BLOCK; // rows per thread in the collection phase
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    __builtin_amdgcn_s_setprio(1);
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
@@ -594,6 +597,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int RPT = WIDE_ROWS / WIDE_BLOCK;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    __builtin_amdgcn_s_setprio(1);
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
@@ -687,9 +691,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                 const bool need16 = __ballot(ok && (vary >> 11)) != 0ull;
                 const bool need11 = __ballot(ok && (vary >> 8)) != 0ull;
                 double res;
+                __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
                 if (need16) res = lane_sym_result<MEASURE, 16>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
                 else if (need11) res = lane_sym_result<MEASURE, 11>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
                 else res = lane_sym_result<MEASURE, 8>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
+                __builtin_amdgcn_s_setprio(1);
                 if (ok) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
@@ -975,6 +981,7 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
 #pragma unroll
         for (int q = 0; q < 4; ++q) step(high_planes(e[q], w, q));
     };
+    __builtin_amdgcn_s_setprio(0); // the step loop yields to waves that are staging their next batch (loads to issue)
     // three words in flight, refilled in turn (no register is copied, so no load is waited for before its turn)
     word_t w2 = fetch(j + 8);
     for (; t + 12u <= T; t += 12u) {
@@ -987,6 +994,7 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
         if (t + 4u <= T) { trip(w0); t += 4u; w0 = w1; }
     }
     for (; t < T; ++t, w0 >>= 8 * UNIT) step(high_planes(trow[((uint32_t)w0 & 31u) * 64u], w0, 0));
+    __builtin_amdgcn_s_setprio(1);
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
     // start at -1 each), hence  D[m][n] = s + n + sum over the job's blocks of popc(Pv) - popc(Mv).
@@ -1471,6 +1479,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     // match table (8 KB), everything else -- staged texts, the scalar-value arrays of the fallback -- lives in a per-wave
     // global workspace (lev_ws, LEV_WS_WORDS words per wave).
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
+    if (LEV) __builtin_amdgcn_s_setprio(1); // wave_lev_blocks lowers it for its step loop
     // Jaro: flags; Jaccard / Dice: the hash table of the multiset intersection (two entries per value)
     constexpr int AUXW = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? WAVE_CAP + 64 : 2 * WAVE_CAP + 64;
     __shared__ uint32_t aux_l[LEV ? 1 : AUXW];
