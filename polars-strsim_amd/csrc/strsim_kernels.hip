@@ -110,6 +110,21 @@ __device__ __forceinline__ uint32_t wave_max_rounded(uint32_t v)
     return C * (g + 1u);
 }
 
+#ifndef STRSIM_LANE_FULL_BARRIERS
+#define STRSIM_LANE_FULL_BARRIERS 0
+#endif
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's global loads and STORES
+// (s_waitcnt vmcnt(0)), which k_lane_pairs does not need -- it communicates through LDS alone -- and which exposes the
+// latency of a block's result stores at the next barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+#if STRSIM_LANE_FULL_BARRIERS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
 
 struct OutPtrs {
@@ -178,7 +193,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
         const uint64_t row0 = blk * LANE_ROWS;
         if (tid < (uint32_t)NBK) s_cnt[par][tid] = 0u;
         if (tid < (uint32_t)LANE_ROUNDS) s_late[par][tid] = 0ull;
-        __syncthreads();
+        lds_barrier();
         // ---- phase 1 (coalesced): offsets -> lengths -> bucket + rank; stage offsets in LDS ---------
         uint32_t key[LANE_RPT], rank[LANE_RPT];
         unsigned long long skip[LANE_RPT]; // per 64-row chunk (q * 4 + wv): rows this kernel will not write
@@ -204,7 +219,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             s_b0[i] = b0;
             s_len[i] = mine ? (la8 | (lb8 << 16)) : 0xFFFFFFFFu;
         }
-        __syncthreads();
+        lds_barrier();
         {
             uint32_t c[NBK];
 #pragma unroll
@@ -217,7 +232,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
                 s_perm[base + rank[q]] = (uint16_t)(q * LANE_BLOCK + tid);
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
 #pragma unroll 1
@@ -278,7 +293,7 @@ __device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ off
             }
             __builtin_amdgcn_s_setprio(1);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
 #pragma unroll
         for (int q = 0; q < LANE_RPT; ++q) {
