@@ -487,7 +487,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 16u) s_cnt[tid] = 0u;
-        __syncthreads();
+        lds_barrier();
         const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
             // ---- collect rows with 33..128-byte strings on the longer side and a non-empty shorter side; key them by
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             uint32_t total = 0;
             {
                 uint32_t c[16];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                     s_list[base + rank[k]] = (uint16_t)(k * WIDE_BLOCK + tid);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- rounds of 64 rows of similar width and length, dealt over the waves (longest first)
             const uint32_t nrounds = (total + 63u) >> 6;
             for (uint32_t rr = wv; rr < nrounds; rr += WIDE_WAVES) {
@@ -556,10 +556,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
 }
