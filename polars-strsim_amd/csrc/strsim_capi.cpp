@@ -64,6 +64,7 @@ struct strsim_ctx {
     static constexpr int RING = 32;
     DevStatus *status = nullptr;      // device, RING entries
     DevStatus *status_host = nullptr; // pinned, RING entries
+    DevStatus *status_host_dev = nullptr; // the same memory as the device addresses it
     hipEvent_t ev[RING][3] = {};
     bool slot_pending[RING] = {};
     bool slot_timed[RING] = {};
@@ -219,6 +220,8 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         e = hipHostMalloc((void **)&c->status_host, sizeof(DevStatus) * strsim_ctx::RING, hipHostMallocDefault);
     if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "status allocation"); }
     memset(c->status_host, 0, sizeof(DevStatus) * strsim_ctx::RING);
+    e = hipHostGetDevicePointer((void **)&c->status_host_dev, c->status_host, 0);
+    if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "hipHostGetDevicePointer"); }
     {   // integer quotients for the epilogues of k_lane_pairs: the host's IEEE division is the device's
         static double q[QTAB_N * QTAB_N];
         for (int a = 0; a < QTAB_N; ++a)
@@ -344,7 +347,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     c->slot_args[slot] = la;
     c->slot_measure[slot] = measure;
     for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = all ? outs[q] : nullptr;
-    HIP_TRY(hipMemcpyAsync(c->status_host + slot, c->status + slot, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->stream));
     c->slot_pending[slot] = true;
     c->head = (slot + 1) % strsim_ctx::RING;
     return STRSIM_OK;

@@ -64,5 +64,7 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
 
 // Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with HUGE_WS_WORDS(cap) words of `ws`.
 hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid);
+// copies one DevStatus to host-mapped pinned memory from the device side (no copy-engine hand-over)
+hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, hipStream_t stream);
 
 } // namespace strsim

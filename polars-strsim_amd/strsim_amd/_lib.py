@@ -31,6 +31,31 @@ class ShapeMismatch(StrsimError, ValueError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    torch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, needed by libtorch_hip.so as plain
+    "libamdhip64.so").  Loaded first, this library binds /opt/rocm's copy; a later `import torch` then maps the bundled
+    copy NEXT to it (its DT_NEEDED name matches neither the path nor the SONAME of the one already there), and the second
+    runtime to initialise reports "No HIP GPUs are available".  Mapping torch's copy before ours makes the loader resolve
+    our DT_NEEDED libamdhip64.so.7 by SONAME to it, and torch finds the same file already mapped.  A process without
+    torch (the Polars plugin route) is not affected and runs on /opt/rocm's runtime.
+    """
+    import sys
+    if "torch" in sys.modules or os.environ.get("STRSIM_KEEP_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -39,6 +64,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` (hipcc, gfx950). "
             "polars-strsim_amd has no Python/CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.strsim_abi_version.restype = C.c_uint32

@@ -1,0 +1,43 @@
+"""One HIP runtime per process, whichever of torch and libpolars_strsim_amd.so is loaded first.
+
+torch wheels bundle their own libamdhip64.so; two runtimes in one process leave the second without a GPU
+("No HIP GPUs are available").  strsim_amd/_lib.py maps torch's copy before the library when torch is installed.
+Fresh interpreters are used because the pytest process may already hold torch.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+MAPS = r"""
+import sys
+sys.path.insert(0, "polars-strsim_amd")
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+import strsim_amd
+strsim_amd.lib()
+import torch
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+print("HIPLIBS", len(libs), libs)
+"""
+
+
+@pytest.mark.parametrize("order", ["lib_first", "torch_first"])
+def test_one_hip_runtime_is_mapped(order):
+    r = subprocess.run([sys.executable, "-c", MAPS, order], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("HIPLIBS")][-1]
+    assert line.split()[1] == "1", line
+
+
+@pytest.mark.gpu
+def test_torch_initialises_after_the_library_has_used_the_gpu():
+    r = subprocess.run([sys.executable, os.path.join(HERE, "torch_after_lib.py"), "2"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "torch init ok" in r.stdout, r.stdout[-2000:]
