@@ -15,7 +15,8 @@ from bench_support import workload as W
 from strsim_amd import arrow_host as H
 
 _, _, law, lo, hi, seed = W.CONFIGS["cfg2"]
-for rows in (1, 100, 10_000, 100_000, 1_000_000):
+SIZES = [int(x) for x in sys.argv[1:]] or [1, 100, 10_000, 100_000, 1_000_000]
+for rows in SIZES:
     oa, va, ob, vb = W.host_columns(seed, law, lo, hi, 0, rows)
     a = pa.StringArray.from_buffers(rows, pa.py_buffer(oa.astype(np.int32)), pa.py_buffer(va)).cast(pa.string_view())
     b = pa.StringArray.from_buffers(rows, pa.py_buffer(ob.astype(np.int32)), pa.py_buffer(vb)).cast(pa.string_view())

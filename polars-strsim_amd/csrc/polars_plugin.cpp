@@ -405,6 +405,7 @@ struct Slot {
     Buf h_off[2], h_val[2], h_out, d_off[2], d_val[2], d_out;
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
+    bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
     Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; } d_out.device = true; }
     void release() { for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); } h_out.release(); d_out.release(); }
 };
@@ -438,6 +439,29 @@ struct ThreadCtx {
     }
 };
 thread_local ThreadCtx g_ctx;
+
+// Small calls: up to this many rows (and direct_bytes() packed bytes per column) the kernels read the pinned staging and write
+// the pinned result buffer through the device's mapping of host memory.  The bytes cross PCIe from inside the kernels
+// instead, but the H2D copies and the D2H copy each cost a hand-over between the copy engine and the compute queue
+// (10-16 us apiece), which is most of a small call: 67 -> 50 us at 1..100 rows, 140 -> 75 us at 4 000, 520 -> 300 us at
+// 30 000, 364 -> 339 us at 100 000; equal at 200 000..500 000 rows and 10 % slower at 1 M, hence the limits.
+uint64_t direct_rows() // read per call: a test (or a user) can switch the path off with POLARS_STRSIM_DIRECT_ROWS=0
+{
+    const char *e = getenv("POLARS_STRSIM_DIRECT_ROWS");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)131072;
+}
+uint64_t direct_bytes()
+{
+    const char *e = getenv("POLARS_STRSIM_DIRECT_BYTES");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)2 << 20;
+}
+
+void *mapped(void *pinned)
+{
+    void *d = nullptr;
+    HIP_OR_FAIL(hipHostGetDevicePointer(&d, pinned, 0));
+    return d;
+}
 
 constexpr uint64_t SLICE_ROWS = 2u << 20;                      // rows packed / shipped / computed per pipeline step
 constexpr uint64_t SLICE_BYTES = (1ull << 32) - (1ull << 24);  // packed values per slice and column (u32 offsets)
@@ -509,6 +533,7 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         strsim_ctx_t *ctx = g_ctx.get();
         hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
         const unsigned T = pack_threads(engine_parallel, n);
+        const bool direct_call = n <= direct_rows();
 
         // a literal side is packed and shipped once
         const uint32_t *lit_off_d = nullptr;
@@ -518,6 +543,11 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
             Buf &ho = g_ctx.lit_h_off, &hv = g_ctx.lit_h_val; // persistent pinned staging: the call is synchronous,
             const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
             if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
+            if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
+                lit_off_d = static_cast<const uint32_t *>(mapped(ho.p));
+                lit_val_d = static_cast<const uint8_t *>(mapped(hv.p));
+                continue;
+            }
             g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
             g_ctx.lit_val.reserve(bytes + 64);
             HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -547,29 +577,38 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
             const uint32_t *doff[2];
             const uint8_t *dval[2];
             uint64_t drows[2];
+            sl.direct = direct_call;
+            for (int s = 0; s < 2; ++s)
+                if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
             for (int s = 0; s < 2; ++s) {
                 if (lit[s]) { doff[s] = lit_off_d; dval[s] = lit_val_d; drows[s] = 1; continue; }
+                drows[s] = sl.rows;
+                if (sl.direct) {
+                    doff[s] = static_cast<const uint32_t *>(mapped(sl.h_off[s].p));
+                    dval[s] = static_cast<const uint8_t *>(mapped(sl.h_val[s].p));
+                    continue;
+                }
                 sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
                 sl.d_val[s].reserve(sl.bytes[s] + 64);
                 HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
                 if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
                 doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
                 dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
-                drows[s] = sl.rows;
             }
-            sl.d_out.reserve(sl.rows * sizeof(double));
             sl.h_out.reserve(sl.rows * sizeof(double));
-            if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1],
-                                    static_cast<double *>(sl.d_out.p), sl.rows) != STRSIM_OK)
+            if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
+            double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
+            if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
                 fail(strsim_last_error_message());
             // results come back right behind the kernels (no separate round trip later)
-            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+            if (!sl.direct)
+                HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
         };
         auto wait = [&](Slot &sl) {
             tm.start();
             if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
             tm.stop(tm.t_wait);
-            if (strsim_ctx_last_long_rows(ctx) != 0) { // rows finished by that pass: fetch the column again
+            if (strsim_ctx_last_long_rows(ctx) != 0 && !sl.direct) { // rows finished by that pass: fetch the column again
                 tm.start();
                 HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
                 HIP_OR_FAIL(hipStreamSynchronize(stream));

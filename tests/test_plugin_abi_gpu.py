@@ -96,6 +96,35 @@ def test_literal_either_side_and_null_cases(H, measure):
     assert H.call_plugin(measure, [], []).to_pylist() == []
 
 
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_small_calls_computed_in_place(H, measure):
+    """Calls of <= 131 072 rows and <= 2 MiB per column: the kernels read the pinned staging and write the pinned result
+    buffer (no copy engine).  Every row class goes through it -- lane, wide, non-ASCII, wave, > 1024-byte strings (second
+    pass) -- plus literals; then the same frames with the path switched off."""
+    A, B = gen.pairs(31, 600, gen.ASCII_LOWER, 0, 32)
+    A2, B2 = gen.pairs(32, 100, gen.MIXED, 0, 200)
+    A3, B3 = gen.pairs(33, 40, gen.ASCII_LOWER, 100, 900)
+    A = ["x" * 1500, "\u00e9" * 700] + A + A2 + A3
+    B = ["x" * 700 + "y" * 700, "e" * 1300] + B + B2 + B3
+    exp = expect(measure, A, B)
+    for n in (1, 2, 3, 63, 64, 65, len(A)):
+        check(H.call_plugin(measure, A[:n], B[:n]), exp[:n])
+    check(H.call_plugin(measure, A, "x" * 1200), expect(measure, A, ["x" * 1200]))
+    check(H.call_plugin(measure, "phillips", B), expect(measure, ["phillips"], B))
+    k = -(-4097 // len(A))
+    An, Bn = (A * k)[:4097], (B * k)[:4097]
+    check(H.call_plugin(measure, An, Bn), (exp * k)[:4097])
+    # the same frames through the copy path (H2D, device buffers, D2H): the limit is read per call
+    import os
+    os.environ["POLARS_STRSIM_DIRECT_ROWS"] = "0"
+    try:
+        check(H.call_plugin(measure, A, B), exp)
+        check(H.call_plugin(measure, A[:3], B[:3]), exp[:3])
+        check(H.call_plugin(measure, A, "x" * 1200), expect(measure, A, ["x" * 1200]))
+    finally:
+        del os.environ["POLARS_STRSIM_DIRECT_ROWS"]
+
+
 def test_threaded_packing_and_multi_slice_pipeline(H):
     """> 2 M rows: several pipeline slices, each packed by helper threads (views with nulls, out-of-line strings)."""
     import sys, os
