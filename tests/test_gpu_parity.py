@@ -311,6 +311,33 @@ def test_fused_all_measures_equals_single_measure_kernels(S):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+def test_host_calls_in_place_and_copied(S, measure, monkeypatch):
+    """strsim_pairs_host: small calls run in place on pinned host memory, larger ones through H2D/D2H copies; both paths on
+    the same mixed frame (every row class, a > 1024-byte row), with offsets that do not start at 0, and a literal side."""
+    A, B = gen.pairs(91, 700, gen.ASCII_LOWER, 0, 32)
+    A2, B2 = gen.pairs(92, 100, gen.MIXED, 0, 200)
+    A3, B3 = gen.pairs(93, 30, gen.ASCII_LOWER, 100, 900)
+    A = ["x" * 1500] + A + A2 + A3
+    B = ["x" * 700 + "y" * 700] + B + B2 + B3
+    exp = O.batch_strings(measure, A, B, 8)
+    ao, av = S.pack_strings(A)
+    bo, bv = S.pack_strings(B)
+    ao7, av7 = (ao + 7).astype(ao.dtype), np.concatenate([np.full(7, 0x7A, np.uint8), av])  # base 7: 7 bytes nobody owns
+    lo, lv = S.pack_strings(["phillips"])
+    exp_lit = O.batch_strings(measure, A, ["phillips"] * len(A), 8)
+    for direct in ("65536", "0"):
+        monkeypatch.setenv("STRSIM_HOST_DIRECT_ROWS", direct)
+        with S.Context(0) as ctx:
+            assert_bit_exact(ctx.pairs_host(measure, ao, av, bo, bv), exp, A, B, "host rows<=%s" % direct)
+            assert_bit_exact(ctx.pairs_host(measure, ao7, av7, bo, bv), exp, A, B, "host base 7, rows<=%s" % direct)
+            assert_bit_exact(ctx.pairs_host(measure, ao, av, lo, lv), exp_lit, A, ["phillips"] * len(A), "host literal")
+            for n in (1, 2, 65):
+                o1, v1 = S.pack_strings(A[:n])
+                o2, v2 = S.pack_strings(B[:n])
+                assert_bit_exact(ctx.pairs_host(measure, o1, v1, o2, v2), exp[:n], A[:n], B[:n], "host n=%d" % n)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_transport_codec_round_trip(S, measure):
     """16-bit codec: decode(encode(x)) == x bit for bit; rows with longer strings travel as exceptions."""
     import torch
