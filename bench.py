@@ -29,8 +29,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    # defaults: the GPU needs ~20 steps (40 ms) of this load before step times settle -- with --warmup 2 --steps 10 the
+    # headline kernel measures 1.89-1.93 ms, from --warmup 10 on 1.71-1.77 ms (same box, back to back)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--config", default="cfg2", help="cfg1|cfg2|cfg3|cfg5 (BASELINE.json configs; cfg2 = headline)")
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's row count)")
     p.add_argument("--measure", default="", help="override the config's measure")

@@ -352,7 +352,9 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;
     if (c->timing) {
         for (int i = 0; i < 3; ++i)
-            if (!c->ev[slot][i]) HIP_TRY(hipEventCreate(&c->ev[slot][i]));
+            // timing only: no system-scope fence when the event completes (a default event costs ~5 us of GPU time
+            // between two kernels, three of them were 1/3 of a 1 M-row call)
+            if (!c->ev[slot][i]) HIP_TRY(hipEventCreateWithFlags(&c->ev[slot][i], hipEventDisableSystemFence));
         la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
     }
     hipError_t e = all ? launch_pairs_all(la, outs, c->slowmask + nchunks) : launch_pairs(measure, la);
