@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "polars_strsim", "libpolars_strsim_amd.so")
+# STRSIM_AMD_LIB: another build of the same library (A/B runs of compile-time variants on one box)
+LIB_PATH = os.environ.get("STRSIM_AMD_LIB") or os.path.join(PKG_DIR, "polars_strsim", "libpolars_strsim_amd.so")
 
 MEASURES = ("levenshtein", "jaro", "jaro_winkler", "jaccard", "sorensen_dice")  # strsim.rs:9-15
 MEASURE_ID = {m: i for i, m in enumerate(MEASURES)}
