@@ -146,11 +146,28 @@ def main():
     assert ctx.stream == compute_stream.cuda_stream
     gather = world > 1 and not a.no_gather
     shipper = None
+    gather_note = None
     if gather:
-        from strsim_amd.distributed import ShardGatherer
-        # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
-        shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend,
-                                codec_chars=32 if (hi <= 32 and not a.no_codec) else None)
+        from strsim_amd.distributed import ShardGatherer, gather_column
+        ok = 1
+        try:
+            # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
+            shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend,
+                                    codec_chars=32 if (hi <= 32 and not a.no_codec) else None)
+            # preflight, outside any timing: one tiny gather over the same call path builds the communicator (so that it is
+            # not built inside the timed region when --warmup is 0) and shows whether this backend can gather at all
+            probe = torch.zeros(64, dtype=torch.uint8, device="cpu" if shipper.host else dev)
+            gather_column(probe, world * 64, dst=0)
+            torch.cuda.synchronize()
+        except Exception as e:  # reported in the JSON line (gather_f64_to_rank0 false + gather_note), never silent
+            ok = 0
+            gather_note = "gather disabled after a failed preflight: " + repr(e)[:300]
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:  # every rank takes the same decision
+            gather, shipper = False, None
+            gather_note = gather_note or "gather disabled: the preflight failed on another rank"
+            print(f"[bench rank {rank}] {gather_note}", file=sys.stderr)
     fused = len(measures) == 5  # cfg4: strsim_pairs_device_all, one fused pass with five outputs
 
     def step(i):
@@ -246,7 +263,7 @@ def main():
                        "rows_per_gpu": rows, "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
-                       "gather_verified": gather_ok,
+                       "gather_verified": gather_ok, "gather_note": gather_note,
                        "rows_on_wave_kernel": wave_rows},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
