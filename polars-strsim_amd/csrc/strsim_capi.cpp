@@ -54,6 +54,8 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
+    int stage_wg_per_cu = 4;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pipe / k_lane_pairs instead of k_lane_stage (A/B runs)
+    int pipe_wg_per_cu = 5;   // STRSIM_PIPE_WG_PER_CU overrides; 0 = use k_lane_pairs instead of k_lane_pipe (A/B runs)
     int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
@@ -63,6 +65,7 @@ struct strsim_ctx {
     // back to back without a host sync; the ring is drained by strsim_ctx_synchronize()
     static constexpr int RING = 32;
     DevStatus *status = nullptr;      // device, RING entries
+    uint32_t *sched = nullptr;        // device, RING x 2 words: work-distribution counters of k_lane_stage (zero between launches)
     DevStatus *status_host = nullptr; // pinned, RING entries
     DevStatus *status_host_dev = nullptr; // the same memory as the device addresses it
     void *pin = nullptr;   // pinned staging of strsim_pairs_host's small calls (kernels work on it in place)
@@ -217,6 +220,14 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         const int v = atoi(env);
         if (v >= 1 && v <= 4096) c->lane_wg_per_cu = v;
     }
+    if (const char *env = getenv("STRSIM_STAGE_WG_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 64) c->stage_wg_per_cu = v;
+    }
+    if (const char *env = getenv("STRSIM_PIPE_WG_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 64) c->pipe_wg_per_cu = v;
+    }
     if (const char *env = getenv("STRSIM_LEV_WAVES_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 256) c->lev_waves_per_cu = v;
@@ -229,6 +240,10 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         c->own_stream = true;
     }
     e = hipMalloc((void **)&c->status, sizeof(DevStatus) * strsim_ctx::RING);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->sched, sizeof(uint32_t) * 2 * strsim_ctx::RING);
+    // (cleared on the context's own stream: a memset on the null stream would bring the legacy default stream into a process
+    //  that may initialise torch's runtime later, tests/test_hip_runtime_sharing.py)
+    if (e == hipSuccess) e = hipMemsetAsync(c->sched, 0, sizeof(uint32_t) * 2 * strsim_ctx::RING, c->stream);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->status_host, sizeof(DevStatus) * strsim_ctx::RING, hipHostMallocDefault);
     if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "status allocation"); }
@@ -258,6 +273,7 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
     for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
     if (c->slowmask) (void)hipFree(c->slowmask);
     if (c->qtab) (void)hipFree(c->qtab);
+    if (c->sched) (void)hipFree(c->sched);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
     if (c->lev_ws) (void)hipFree(c->lev_ws);
     if (c->status) (void)hipFree(c->status);
@@ -329,9 +345,12 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
     la.out = outs[0]; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
+    la.sched = c->sched + 2 * slot;
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
     la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
+    la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
+    la.pipe_grid = c->pipe_wg_per_cu > 0 ? c->num_cu * c->pipe_wg_per_cu : 0;
     la.wide_grid = c->num_cu * 3; // resident (LDS)
     {
         int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)

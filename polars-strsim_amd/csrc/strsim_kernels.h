@@ -49,8 +49,11 @@ struct LaunchArgs {
     uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
     const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of k_lane_pairs (device)
     DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
+    uint32_t *sched;              // k_lane_stage: two zeroed words (range counter, finished workgroups); left zeroed by the kernel
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
+    int stage_grid;               // > 0: k_lane_stage (bytes staged through LDS) with this many persistent workgroups
+    int pipe_grid;                // > 0: k_lane_pipe (persistent, software-pipelined) with this many workgroups instead of k_lane_pairs
     int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
     uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words

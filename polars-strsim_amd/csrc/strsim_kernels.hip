@@ -32,45 +32,9 @@
 #include "strsim_lane_wide.h"
 #include "strsim_lane_sym.h"
 #include "strsim_kernels.h"
+#include "strsim_lane_common.h"
 
 namespace strsim {
-
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-// 32-byte window vals[off, off+32) into w[0..7]; bytes at or beyond `total` read as 0.
-__device__ __forceinline__ void load_window32(const uint8_t *__restrict__ vals, uint32_t off, uint32_t total,
-                                              uint32_t (&w)[8])
-{
-    const uint8_t *p = vals + off;
-    if (total - off >= 32u) {
-        const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
-        const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
-        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-        w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
-    } else {
-        const uint32_t avail = total - off; // < 32
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            uint32_t v = 0u;
-            if (avail >= 4u * d + 4u) {
-                v = *reinterpret_cast<const u32_unaligned *>(p + 4 * d);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (avail > 4u * d + k) v |= (uint32_t)p[4 * d + k] << (8 * k);
-            }
-            w[d] = v;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes, match masks and DP state in registers.
@@ -97,33 +61,6 @@ constexpr int LANE_RPW = STRSIM_LANE_RPW;        // rounds per wave and block (e
 constexpr int LANE_ROUNDS = LANE_RPW * LANE_WAVES; // rounds of 64 rows per block (8)
 constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
 constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coalesced phases (2)
-
-// COLS_PER_TEST * ceil(max over the wave of v / COLS_PER_TEST), at least COLS_PER_TEST (v <= 32): a binary search
-// with ballots, result in an SGPR
-__device__ __forceinline__ uint32_t wave_max_rounded(uint32_t v)
-{
-    constexpr uint32_t C = (uint32_t)COLS_PER_TEST;
-    uint32_t g = 0; // groups of C columns below the answer
-#pragma unroll
-    for (uint32_t half = 16u / C; half >= 1u; half >>= 1)
-        if (__ballot(v > C * (g + half)) != 0ull) g += half;
-    return C * (g + 1u);
-}
-
-#ifndef STRSIM_LANE_FULL_BARRIERS
-#define STRSIM_LANE_FULL_BARRIERS 0
-#endif
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's global loads and STORES
-// (s_waitcnt vmcnt(0)), which k_lane_pairs does not need -- it communicates through LDS alone -- and which exposes the
-// latency of a block's result stores at the next barrier.
-__device__ __forceinline__ void lds_barrier()
-{
-#if STRSIM_LANE_FULL_BARRIERS
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
 
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
 
@@ -332,6 +269,9 @@ k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
 {
     lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
 }
+
+#include "strsim_lane_pipe.h"
+#include "strsim_lane_stage.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_wide: one pair per lane for the rows k_lane_pairs left behind whose strings are 33..128 ASCII
@@ -1864,8 +1804,26 @@ static void launch_pair(const LaunchArgs &a)
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
-    hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
+    if (a.stage_grid > 0) {
+        // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
+        const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
+        const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;
+        hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab, a.sched);
+    } else if (a.pipe_grid > 0) {
+        // software-pipelined form (strsim_lane_pipe.h): persistent workgroups, one per resident slot
+        const uint64_t npb = (a.n + (PIPE_ROWS - 1)) / PIPE_ROWS;
+        const uint64_t gp = npb < (uint64_t)a.pipe_grid ? npb : (uint64_t)a.pipe_grid;
+        if (a.rowsA == 1 || a.rowsB == 1)
+            hipLaunchKernelGGL((k_lane_pipe<M, true>), dim3((unsigned)gp), dim3(PIPE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                               a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab);
+        else
+            hipLaunchKernelGGL((k_lane_pipe<M, false>), dim3((unsigned)gp), dim3(PIPE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                               a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab);
+    } else {
+        hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
+    }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     {
         uint32_t sps;
@@ -1982,3 +1940,23 @@ hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, hi
 }
 
 } // namespace strsim
+
+#ifdef STRSIM_PIPE_STAMPS
+// diagnostic build only: copies the per-wave phase cycle sums of the last k_lane_pipe launch to the host
+extern "C" __attribute__((visibility("default"))) int strsim_debug_pipe_stamps(unsigned long long *dst, size_t waves)
+{
+    if (waves > 16384) waves = 16384;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(strsim::g_pipe_stamps), waves * 10 * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
+
+#ifdef STRSIM_STAGE_STAMPS
+// diagnostic build only: copies the per-wave phase cycle sums of the last k_lane_stage launch to the host
+extern "C" __attribute__((visibility("default"))) int strsim_debug_stage_stamps(unsigned long long *dst, size_t waves)
+{
+    if (waves > 16384) waves = 16384;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(strsim::g_stage_stamps), waves * 16 * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif

@@ -1,0 +1,467 @@
+// strsim_lane_stage.h -- k_lane_stage<M>: the one-pair-per-lane kernel for strings of <= 32 ASCII bytes with the
+// string bytes STAGED THROUGH LDS.  Included by strsim_kernels.hip inside namespace strsim, after its helpers.
+//
+// Same per-pair arithmetic as k_lane_pairs (strsim_lane_core.h; reference strsim.rs:125-162, :180-245, :257-272,
+// :286-308, :322-345).  What changes is how the bytes reach the lanes.  k_lane_pairs has every lane pull its two
+// 32-byte windows with unaligned 16-byte global loads in length-sorted (= scattered) order: 4 load instructions of 64
+// different cache-line pairs each per 64 pairs, which keeps the CU's texture-address unit busy ~600 cycles per 64
+// pairs -- the unit, not the VALU and not HBM, is what bounds that kernel (TA_BUSY ~ kernel time).  Here
+// a workgroup copies the CONTIGUOUS byte range of its block of rows from both value buffers into LDS with coalesced
+// 16-byte-per-lane LDS-DMA loads (global_load_lds_dwordx4: every 128-byte line crosses the address unit once and
+// never touches a VGPR) and the lanes then pick their windows out of LDS with two unaligned ds_read_b128 each.
+//
+//   per block of STAGE_ROWS consecutive rows (persistent 256-thread workgroup, grid-stride over blocks):
+//     A  bytes DMA(j)      both columns' byte ranges of block j -> s_bytes (in flight during B and C)
+//     B  store(j-1)        results of block j-1, staged in LDS by its rounds, leave as coalesced 8-byte stores
+//     C  sortA/sortB(j)    offsets (in LDS since the previous block's rounds) -> lengths -> bucket by the number of
+//                          DP columns -> rank by LDS atomics | barrier | wave scan of the counters -> 8-byte
+//                          descriptors in length order
+//     D  wait for the DMA, barrier
+//     E  offsets DMA(j+1)  the next block's 2 x (STAGE_ROWS + 1) offsets -> s_off (in flight during F)
+//     F  rounds(j)         wave w: rounds w and NR-1-w, ... of 64 pairs of similar length: descriptor -> two windows
+//                          from LDS -> bit-parallel cores in registers -> result code (Levenshtein) / f64 into LDS
+//     G  barrier
+//   Three LDS-only barriers per block.  Blocks are cut to fit: a workgroup owns a contiguous range of 64-row chunks and
+//   takes as many of the next chunks (at most STAGE_ROWS / 64) as have their bytes inside the staging area, so data
+//   with longer rows simply runs in smaller blocks.  Rows longer than 32 bytes, non-ASCII rows and rows of a single
+//   chunk that alone overflows the staging area stay in the mask for the later kernels, as with k_lane_pairs.
+#pragma once
+
+#ifndef STRSIM_STAGE_ROWS
+#define STRSIM_STAGE_ROWS 512
+#endif
+#ifndef STRSIM_STAGE_CAP
+#define STRSIM_STAGE_CAP 10240 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB)
+#endif
+#ifndef STRSIM_STAGE_WAVES_PER_EU
+#define STRSIM_STAGE_WAVES_PER_EU 4
+#endif
+#ifndef STRSIM_STAGE_BUCKET_SHIFT
+#define STRSIM_STAGE_BUCKET_SHIFT 1
+#endif
+
+#ifdef STRSIM_STAGE_STAMPS
+// diagnostic build only (never in the product library): per-wave cycle sums of the phases of k_lane_stage, read back with
+// strsim_debug_stage_stamps().  [0] block cut + bytes DMA issue [1] store [2] sortA [3] barrier [4] sortB [5] DMA wait +
+// barrier [6] offsets DMA issue [7] rounds: descriptor + windows [8] rounds: cores [9] barrier G [10] all [11] all (100 MHz)
+__device__ unsigned long long g_stage_stamps[16384][16]; // [12], [13]: s_memrealtime at the wave's start and end
+#define STAGE_STAMP(cat) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                              __builtin_amdgcn_sched_barrier(0); st_acc[cat] += t_ - st_last; st_last = t_; } while (0)
+#elif defined(STRSIM_STAGE_FENCES)
+#define STAGE_STAMP(cat) do { __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAGE_STAMP(cat) do { } while (0)
+#endif
+
+constexpr int STAGE_BLOCK = 256;                      // threads per workgroup
+constexpr int STAGE_WAVES = STAGE_BLOCK / 64;         // 4
+constexpr int STAGE_ROWS = STRSIM_STAGE_ROWS;         // rows per block
+constexpr int STAGE_RPT = STAGE_ROWS / STAGE_BLOCK;   // rows per thread in the coalesced phases
+constexpr int STAGE_NR = STAGE_ROWS / 64;             // rounds per block
+constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and block
+constexpr int STAGE_CAP = STRSIM_STAGE_CAP;           // staged bytes per column
+constexpr int STAGE_COL = STAGE_CAP + 64;             // LDS bytes per column (a window may start at the last staged byte)
+constexpr int STAGE_DMA_ITERS = (STAGE_CAP + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
+constexpr int STAGE_BSH = STRSIM_STAGE_BUCKET_SHIFT;  // buckets of 2^BSH column counts
+constexpr int STAGE_NBK = (32 >> STAGE_BSH) + 1;      // + one for the rows this kernel leaves to the later ones
+static_assert(STAGE_RPT >= 1 && STAGE_RPT <= 4 && STAGE_RPW >= 1, "STAGE_ROWS is 256, 512 or 1024");
+static_assert(STAGE_CAP % 1024 == 0 && 2 * STAGE_COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
+static_assert(STAGE_NBK <= 32, "the bucket scan runs on 32 lanes");
+
+// LDS byte address of a __shared__ object (what M0 / a DS instruction's address operand hold)
+#define STRSIM_LDS_ADDR(p) ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) void *)(p)))
+
+// LDS-DMA: each active lane copies SIZE bytes from its own global address to lds_dst + lane * SIZE (lds_dst uniform).
+// Inline asm on purpose: hipcc orders every later LDS access behind a __builtin_amdgcn_global_load_lds it knows about with
+// s_waitcnt vmcnt(0) (it cannot tell the arrays apart), which would serialise exactly the overlap this kernel is built for.
+// The kernel waits for its DMAs itself: s_waitcnt vmcnt(0) + workgroup barrier before the first read of the data.
+// M0 (the LDS base of the DMA) is saved and restored inside the statement; s_nop 0: SALU write of M0 -> LDS-DMA read.
+__device__ __forceinline__ void lds_dma_b128(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma_b32(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// a load the compiler may do on the scalar unit: the offsets are never written while the kernel runs (constant address
+// space = invariant memory; a plain load behind the kernel's own stores becomes a vector load + s_waitcnt vmcnt(0))
+__device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
+{
+    return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(reinterpret_cast<uintptr_t>(p));
+}
+
+// Descriptor of a row, 8 bytes, written in length order by sortB:
+//   x = text window | pattern window << 16: byte index into s_bytes (staging areas of a and b, the literals' copies)
+//   y = text length | pattern length << 8 | row index within the block << 16 | not mine << 31
+// "text" is the string the columns of the bit-parallel cores walk: a, or the shorter one for the symmetric measures
+// when both sides are columns.
+constexpr uint32_t STAGE_DEAD = 1u << 31;
+
+__device__ __forceinline__ void stage_lds32(const uint8_t *p, uint32_t (&w)[8])
+{
+    const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
+    const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
+    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+    w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+}
+
+// Levenshtein result as an index into the 33 x 33 table of 1 - dist/den (dist * 33 + den); 0xFFFF is never produced
+template <int NP>
+__device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
+                                                   uint32_t tmax)
+{
+    uint32_t P[NP];
+    build_planes<NP>(wb, P);
+    const bool live = la != 0u && lb != 0u;
+    const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
+    const uint32_t s = 32u - lb1;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) P[k] <<= s;
+    const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
+    uint32_t code = dist * 33u + (la1 > lb1 ? la1 : lb1);
+    // both empty: 1.0 = entry (0, 1); one side empty: 0.0 = entry (1, 1)   (strsim.rs:128, :160)
+    if (!live) code = (la == 0u && lb == 0u) ? 1u : 34u;
+    return code;
+}
+
+template <int MEASURE>
+__device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta, uint16_t *s_code,
+                                              double *s_val, const double *__restrict__ qtab)
+{
+    bool fast = (meta & STAGE_DEAD) == 0u;
+    const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
+    // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any high bit leaves
+    // the row to the code-point kernels; the varying low bits decide how many bit-planes the match masks need
+    uint32_t any;
+    const uint32_t vary = window_vary(wt, wp, any);
+    if (any & 0x80u) fast = false;
+    if (__ballot(fast) == 0ull) return;
+    const uint32_t la = fast ? lt : 0u, lb = fast ? lp : 0u;
+    const uint32_t tmax = wave_max_rounded(la);
+    const bool wide = __ballot(fast && (vary & 0x60u)) != 0ull; // six-plane rounds run as seven (register budget)
+    if (MEASURE == LEVENSHTEIN) {
+        uint32_t code;
+        if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmax);
+        else code = stage_lev_code<5>(wt, la, wp, lb, tmax);
+        if (fast) s_code[idx] = (uint16_t)code;
+    } else {
+        double res;
+        if (wide) res = lane_pair_result<MEASURE, 7>(wt, la, wp, lb, tmax, nullptr, qtab);
+        else res = lane_pair_result<MEASURE, 5>(wt, la, wp, lb, tmax, nullptr, qtab);
+        if (fast) s_val[idx] = res;
+    }
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_WAVES_PER_EU))) void
+k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
+             const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, double *__restrict__ out,
+             uint64_t n, unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
+             const double *__restrict__ qtab, uint32_t *__restrict__ sched)
+{
+    constexpr bool LEV = MEASURE == LEVENSHTEIN;
+    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
+    constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
+    constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 64]; // offsets of the rows from the next block's start on
+    __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
+    __shared__ uint2 s_desc[B];
+    __shared__ uint16_t s_code[LEV ? B : 1];   // Levenshtein: table index per row, 0xFFFF = not computed here
+    __shared__ double s_val[LEV ? 1 : B];      // other measures: the f64 result, all-ones = not computed here
+    __shared__ double s_levtab[LEV ? 33 * 33 : 1];
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
+    if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
+    if (LEV) {
+        // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: the epilogue's own IEEE division
+        // (strsim.rs:160), done once per workgroup instead of once per pair
+        for (uint32_t i = tid; i < 33u * 33u; i += STAGE_BLOCK) {
+            const uint32_t d = i / 33u, m = i % 33u;
+            s_levtab[i] = m ? epilogue_levenshtein(d, m, m) : 0.0;
+        }
+    }
+    if (tid < 32u) s_cnt[tid] = 0u;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
+        if (LEV) s_code[i] = 0xFFFFu;
+        else reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;
+    }
+
+    const uint32_t totalA = load_invariant(offA + rowsA), totalB = load_invariant(offB + rowsB);
+    const bool bcastA = rowsA == 1, bcastB = rowsB == 1; // a one-row side is the literal (strsim.rs:48-52, :61-66)
+    const uint32_t litA0 = bcastA ? load_invariant(offA) : 0u, litB0 = bcastB ? load_invariant(offB) : 0u;
+    const uint32_t litAlen = bcastA ? totalA - litA0 : 0u, litBlen = bcastB ? totalB - litB0 : 0u;
+    if (wv == 0u) {
+        // the literals' 32-byte windows, zero-padded, behind the two staging areas
+        uint32_t w[8];
+        if (bcastA) {
+            load_window32(valA, litA0, totalA, w);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t *>(s_bytes + LIT)[q] = w[q];
+        }
+        if (bcastB) {
+            load_window32(valB, litB0, totalB, w);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t *>(s_bytes + LIT + 32u)[q] = w[q];
+        }
+    }
+    // Work distribution: ranges of 64-row chunks handed out by a device-wide counter (sched[0]; sched[1] counts the
+    // workgroups that have finished, the last one clears both for the next launch).  A static split would do if all
+    // workgroups ran equally fast, but the SIMD serves its OLDEST wave first, so of the four workgroups resident on a CU
+    // the first finishes its share at 57 % of the kernel's time and the last one runs alone at the end (measured: ends at
+    // 1.15 / 1.40 / 1.70 / 2.01 ms of a 2.05 ms launch).  The size of a range shrinks with the work that is left
+    // (remaining / (2 x workgroups), between one block and 256 chunks), so all workgroups end within about a block.
+    const uint64_t nchunks = (n + 63u) >> 6;
+    auto grab = [&](uint32_t seen, uint32_t &lo, uint32_t &sz) { // thread 0 only
+        const uint64_t left = nchunks > seen ? nchunks - seen : 0u;
+        uint64_t want = left / (2u * (uint64_t)gridDim.x);
+        want = want < (uint64_t)(B / 64) ? (uint64_t)(B / 64) : (want > 256u ? 256u : want);
+        sz = (uint32_t)want;
+        lo = atomicAdd(&sched[0], sz);
+    };
+    uint32_t grab_lo = 0u, grab_sz = 0u; // thread 0: the range after the next one, on its way
+    if (tid == 0u) {
+        grab(0u, grab_lo, grab_sz);
+        s_sched[0] = grab_lo;
+        s_sched[1] = grab_sz;
+    }
+    lds_barrier();
+    uint64_t row_end; // first row behind the current range
+    uint64_t row0;    // first row of the block about to be processed
+    {
+        const uint64_t lo = s_sched[0], hi = lo + s_sched[1];
+        row0 = lo * 64u < n ? lo * 64u : n;
+        row_end = hi * 64u < n ? hi * 64u : n;
+    }
+    lds_barrier();
+    if (tid == 0u) grab(grab_lo, grab_lo, grab_sz); // (written to s_sched at the top of the first block)
+    bool grab_pending = true;
+
+    const uint32_t ldsOffA = STRSIM_LDS_ADDR(&s_off[0][0]), ldsOffB = STRSIM_LDS_ADDR(&s_off[1][0]);
+    const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0]);
+    const uint32_t wvu = uniform(wv);
+    // offsets DMA: the offsets of rows row .. row + min(B, row_end - row) (one more than rows) of each column side that
+    // is not a literal -> s_off[side][0 ..]
+    auto dma_offsets = [&](uint64_t row) {
+        const uint32_t cnt = (uint32_t)(row_end - row < (uint64_t)B ? row_end - row : (uint64_t)B); // rows available
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) {
+            const uint32_t c = (uint32_t)it * STAGE_BLOCK + tid;
+            if (c <= cnt) {
+                if (!bcastA) lds_dma_b32(offA + row + c, ldsOffA + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                if (!bcastB) lds_dma_b32(offB + row + c, ldsOffB + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+            }
+        }
+        if (tid == 0u && cnt == (uint32_t)B) { // the offset behind the last row of a full block
+            if (!bcastA) lds_dma_b32(offA + row + B, ldsOffA + 4u * (uint32_t)B);
+            if (!bcastB) lds_dma_b32(offB + row + B, ldsOffB + 4u * (uint32_t)B);
+        }
+    };
+
+    uint64_t prev_row0 = 0;           // the block whose results are waiting in LDS
+    uint32_t prev_rows = 0;
+    if (row0 < row_end) dma_offsets(row0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    // store(j-1): staged results -> global, coalesced; rows nobody computed go into the mask word of their chunk
+    auto store_block = [&](uint64_t r0, uint32_t rows) {
+        double *__restrict__ const outb = out + r0;
+        unsigned long long *__restrict__ const maskb = slowmask + (r0 >> 6);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
+            if ((uint32_t)q * STAGE_BLOCK < rows) { // (uniform)
+                bool undone;
+                double v;
+                if (LEV) {
+                    const uint32_t code = s_code[i];
+                    s_code[i] = 0xFFFFu;
+                    undone = code == 0xFFFFu;
+                    v = s_levtab[undone ? 0u : code];
+                } else {
+                    v = s_val[i];
+                    reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;
+                    undone = (uint32_t)(__double_as_longlong(v) >> 32) == 0xFFFFFFFFu;
+                }
+                const bool valid = i < rows;
+                const unsigned long long left = __ballot(undone && valid);
+                if (valid && !undone) outb[i] = v;
+                if (lane == 0u && valid) maskb[i >> 6] = left;
+            }
+        }
+    };
+
+#ifdef STRSIM_STAGE_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_last = st_t0;
+#endif
+    while (row0 < row_end) {
+        if (grab_pending) { // the range grabbed when this one was entered: publish it (read behind at least one barrier)
+            if (tid == 0u) {
+                s_sched[0] = grab_lo;
+                s_sched[1] = grab_sz;
+            }
+            grab_pending = false;
+        }
+        // ---- the block: as many of the next 64-row chunks (at most B / 64) as have their bytes inside the staging areas
+        const uint32_t avail = (uint32_t)(row_end - row0 < (uint64_t)B ? row_end - row0 : (uint64_t)B); // rows whose offsets are in s_off
+        const uint32_t baseA = bcastA ? litA0 : s_off[0][0], baseB = bcastB ? litB0 : s_off[1][0];
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(valA + baseA) & 15u);
+        const uint32_t misB = (uint32_t)(reinterpret_cast<uintptr_t>(valB + baseB) & 15u);
+        uint32_t rows;
+        {
+            // lane c < B / 64: does the block still fit if it ends behind chunk c?
+            const uint32_t e = (lane + 1u) * 64u < avail ? (lane + 1u) * 64u : avail; // rows if the block ends behind chunk `lane`
+            const bool exists = lane * 64u < avail && lane < (uint32_t)(B / 64);
+            const uint32_t endA = bcastA ? baseA : s_off[0][exists ? e : 0u], endB = bcastB ? baseB : s_off[1][exists ? e : 0u];
+            const bool fits = exists && endA - baseA + misA <= (uint32_t)STAGE_CAP && endB - baseB + misB <= (uint32_t)STAGE_CAP;
+            const unsigned long long okm = __ballot(fits);
+            // chunks 0 .. k-1 fit: k = number of trailing ones; at least one chunk is taken even if it overflows
+            uint32_t k = (uint32_t)__builtin_ctzll(~okm);
+            if (k == 0u) k = 1u;
+            rows = k * 64u < avail ? k * 64u : avail;
+        }
+        const uint32_t endA = bcastA ? baseA : uniform(s_off[0][rows]), endB = bcastB ? baseB : uniform(s_off[1][rows]);
+        // ---- A: bytes DMA(j).  Column side X: the 16-byte chunks from the aligned address below the block's first byte
+        //         up to the block's last byte, at most STAGE_CAP bytes -> s_bytes[X]
+        const uint32_t spanA = endA - baseA + misA, spanB = endB - baseB + misB;
+        const uint32_t chunksA = bcastA ? 0u : ((spanA < (uint32_t)STAGE_CAP ? spanA : (uint32_t)STAGE_CAP) + 15u) >> 4;
+        const uint32_t chunksB = bcastB ? 0u : ((spanB < (uint32_t)STAGE_CAP ? spanB : (uint32_t)STAGE_CAP) + 15u) >> 4;
+        {
+            const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
+#pragma unroll
+            for (int it = 0; it < STAGE_DMA_ITERS; ++it) {
+                const uint32_t c = (uint32_t)it * STAGE_BLOCK + tid;
+                if (c < chunksA) lds_dma_b128(gA + 16u * c, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                if (c < chunksB) lds_dma_b128(gB + 16u * c, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+            }
+        }
+        STAGE_STAMP(0);
+        // ---- B: store(j-1)
+        if (prev_rows) store_block(prev_row0, prev_rows);
+        STAGE_STAMP(1);
+        // ---- C: sortA(j): lengths -> bucket keys (number of DP columns the pair will run), ranks by LDS atomics
+        uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT];
+        {
+            const uint32_t stagedA = chunksA << 4, stagedB = chunksB << 4;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const uint32_t i = (uint32_t)RPT * tid + (uint32_t)q;
+                const bool have = i < rows;
+                const uint32_t a0 = bcastA ? 0u : s_off[0][i] - baseA, b0 = bcastB ? 0u : s_off[1][i] - baseB;
+                const uint32_t la8 = bcastA ? litAlen : s_off[0][i + 1u] - s_off[0][i];
+                const uint32_t lb8 = bcastB ? litBlen : s_off[1][i + 1u] - s_off[1][i];
+                // mine: both strings <= 32 bytes and inside what was copied to the staging areas (the literal has its own copy)
+                const bool stA = bcastA || misA + a0 + la8 <= stagedA, stB = bcastB || misB + b0 + lb8 <= stagedB;
+                const bool mine = have && la8 <= 32u && lb8 <= 32u && stA && stB;
+                const uint32_t wa = bcastA ? LIT : misA + a0, wb = bcastB ? LIT + 32u : COLB + misB + b0;
+                const bool swap = SYMMETRIC && !bcastA && !bcastB && la8 > lb8; // symmetric measures walk the shorter string
+                const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
+                const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
+                skey[q] = key;
+                srank[q] = atomicAdd(&s_cnt[key], 1u);
+                sd0[q] = mine ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
+                sd1[q] = mine ? (lt | (lp << 8) | (i << 16)) : STAGE_DEAD;
+            }
+        }
+        STAGE_STAMP(2);
+        lds_barrier();
+        STAGE_STAMP(3);
+        // ---- C: sortB(j): exclusive scan of the bucket counters (every wave for itself), descriptors in length order
+        uint32_t nmine;
+        {
+            const uint32_t c = s_cnt[lane & 31u];
+            uint32_t inc = c;
+#pragma unroll
+            for (int sft = 1; sft < 32; sft <<= 1) {
+                const uint32_t up = __shfl_up(inc, sft, 32);
+                if ((lane & 31u) >= (uint32_t)sft) inc += up;
+            }
+            const uint32_t exc = inc - c;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const uint32_t base = __shfl(exc, skey[q], 32);
+                s_desc[base + srank[q]] = make_uint2(sd0[q], sd1[q]);
+            }
+            nmine = uniform(__shfl(exc, NBK - 1, 32));
+        }
+        STAGE_STAMP(4);
+        // ---- D: the bytes have landed (every wave waits for its own DMA, the barrier makes that workgroup-wide)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        STAGE_STAMP(5);
+        if (tid < 32u) s_cnt[tid] = 0u; // read by sortB above, next used by sortA behind barrier G
+        // ---- E: offsets DMA(j+1), in flight during the rounds
+        uint64_t next_row0 = row0 + rows;
+        if (next_row0 >= row_end) { // this range is done: move to the next one and ask for the one after it
+            const uint64_t lo = s_sched[0], hi = lo + s_sched[1];
+            next_row0 = lo * 64u < n ? lo * 64u : n;
+            row_end = hi * 64u < n ? hi * 64u : n;
+            if (tid == 0u) grab((uint32_t)lo, grab_lo, grab_sz);
+            grab_pending = true;
+        }
+        if (next_row0 < row_end) dma_offsets(next_row0);
+        STAGE_STAMP(6);
+        // ---- F: rounds(j): wave w runs rounds w, 2W-1-w, 2W+w, ... of the length order (short + long = balanced)
+#pragma unroll 1
+        for (int k = 0; k < STAGE_RPW; ++k) {
+            const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+            if (r * 64u >= nmine) continue;
+            const uint2 d = s_desc[r * 64u + lane];
+            uint32_t wt[8], wp[8];
+            stage_lds32(s_bytes + (d.x & 0xFFFFu), wt);
+            stage_lds32(s_bytes + (d.x >> 16), wp);
+#if defined(STRSIM_STAGE_STAMPS) || defined(STRSIM_STAGE_LGKM)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            STAGE_STAMP(7);
+            stage_compute<MEASURE>(wt, wp, d.y, s_code, s_val, qtab);
+            STAGE_STAMP(8);
+        }
+        // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        STAGE_STAMP(9);
+        prev_row0 = row0;
+        prev_rows = rows;
+        row0 = next_row0;
+    }
+    if (prev_rows) store_block(prev_row0, prev_rows);
+    if (tid == 0u) {
+        // the last workgroup to leave clears the counters for the next launch on this slot
+        const uint32_t done = atomicAdd(&sched[1], 1u);
+        if (done == gridDim.x - 1u) {
+            __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#ifdef STRSIM_STAGE_STAMPS
+    if (lane == 0u) {
+        const uint32_t w = (blockIdx.x * STAGE_WAVES + wv) & 16383u;
+        for (int q = 0; q < 10; ++q) g_stage_stamps[w][q] = st_acc[q];
+        g_stage_stamps[w][10] = __builtin_amdgcn_s_memtime() - st_t0;
+        const unsigned long long st_r1 = __builtin_amdgcn_s_memrealtime();
+        g_stage_stamps[w][11] = st_r1 - st_r0;
+        g_stage_stamps[w][12] = st_r0;
+        g_stage_stamps[w][13] = st_r1;
+        g_stage_stamps[w][14] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        g_stage_stamps[w][15] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+    }
+#endif
+}
