@@ -8,6 +8,12 @@
 #include <cstdint>
 #include "strsim_lane_core.h"
 
+#ifndef CORE
+#define CORE 0
+#endif
+#ifndef TMIN
+#define TMIN 29u
+#endif
 #ifndef VALU_PER_ITER
 #define VALU_PER_ITER 800
 #endif
@@ -27,7 +33,13 @@ __global__ __launch_bounds__(64) void k(uint32_t *out, unsigned long long *clk, 
     for (int i = 0; i < iters; ++i) {
         uint32_t P[5];
         build_planes<5>(wb, P);
+#if CORE == 0
         const uint32_t dist = lev_myers32<5>(wa, 32u, 32u, P, 32u);
+#elif CORE == 1
+        const uint32_t dist = lev_myers32_snap<5>(wa, 29u + (threadIdx.x & 3u), TMIN, 32u, P, 32u);
+#else
+        const uint32_t dist = P[0] ^ P[1] ^ P[2] ^ P[3] ^ P[4]; // planes only
+#endif
         acc += dist;
         wa[0] ^= dist; // the next iteration depends on this one
         wb[7] += dist;
@@ -42,7 +54,7 @@ int main()
     hipDeviceProp_t p;
     (void)hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
-    for (int w : {1, 2, 3, 4, 5, 6, 8}) {
+    for (int w : {2, 4, 8}) {
         const int blocks = cus * 4 * w; // one wave per block
         uint32_t *d;
         unsigned long long *c;
@@ -66,8 +78,8 @@ int main()
         cyc /= blocks; rt /= blocks;
         const double ghz = cyc / rt * 0.1;
         const double ops = (double)blocks * iters * (double)VALU_PER_ITER;
-        printf("waves/SIMD=%d: %.3f ms, clock %.2f GHz, %.1f cycles per iteration per wave, %.3f VALU per cycle per SIMD (wave lifetime), %.3f (wall @ that clock)\n",
-               w, ms, ghz, cyc / iters, (double)w * VALU_PER_ITER / (cyc / iters), ops / (cus * 4.0) / (ms * 1e-3 * ghz * 1e9));
+        printf("core %d waves/SIMD=%d: %.3f ms, clock %.2f GHz, %.0f cycles of SIMD time per iteration (= per 64 pairs of 32 columns), %.3f VALU per cycle per SIMD\n",
+               CORE, w, ms, ghz, ms * 1e-3 * ghz * 1e9 / ((double)iters * w), ops / (cus * 4.0) / (ms * 1e-3 * ghz * 1e9));
         delete[] h;
         (void)hipFree(d); (void)hipFree(c);
     }

@@ -9,7 +9,7 @@ PASSES=(
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"
  "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
- "SQ_IFETCH SQC_ICACHE_MISSES SQC_ICACHE_REQ SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_SMEM"
+ "SQ_IFETCH SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INSTS_SMEM"
 )
 i=0
 for P in "${PASSES[@]}"; do
@@ -21,7 +21,7 @@ import csv,sys,collections
 acc=collections.defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if "k_lane_p" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in ("k_lane_pairs", "k_lane_pipe", "k_lane_stage")): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 except Exception as e:
     print("  (no counters: %r)" % (e,))
 rows=float(sys.argv[2])

@@ -104,14 +104,17 @@ STRSIM_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
 
 // 8x8 bit-matrix transpose of the eight bytes {lo, hi}: afterwards byte k holds bit k of the eight
 // source bytes (bit i of byte k = bit k of source byte i).  Three block-swap rounds (1, 2, 4 bits).
+// (written with explicit three-input ops: (a ^ b) & c = 0x28, a ^ b ^ c = 0x96 -- hipcc does not form v_bitop3_b32 from
+// plain C, and on gfx950 v_bitop3_b32 issues at the full rate like v_xor while a left shift costs two slots,
+// bench_support/micro/op_cost.hip)
 STRSIM_HD void transpose8x8(uint32_t &lo, uint32_t &hi)
 {
     uint32_t t;
-    t = (lo ^ (lo >> 7)) & 0x00AA00AAu; lo = lo ^ t ^ (t << 7);
-    t = (hi ^ (hi >> 7)) & 0x00AA00AAu; hi = hi ^ t ^ (t << 7);
-    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
-    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
-    t = (lo ^ (hi << 4)) & 0xF0F0F0F0u;
+    t = bitop3<0x28>(lo, lo >> 7, 0x00AA00AAu); lo = bitop3<0x96>(lo, t, t << 7);
+    t = bitop3<0x28>(hi, hi >> 7, 0x00AA00AAu); hi = bitop3<0x96>(hi, t, t << 7);
+    t = bitop3<0x28>(lo, lo >> 14, 0x0000CCCCu); lo = bitop3<0x96>(lo, t, t << 14);
+    t = bitop3<0x28>(hi, hi >> 14, 0x0000CCCCu); hi = bitop3<0x96>(hi, t, t << 14);
+    t = bitop3<0x28>(lo, hi << 4, 0xF0F0F0F0u);
     lo ^= t;
     hi ^= t >> 4;
 }
@@ -228,6 +231,68 @@ STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tm
     // column j sits at history bit nit-1-j; keep columns 0..lt-1
     const uint32_t cols = low_ones(lt) << (nit - lt);
     return lp + popc32(hp & cols) - popc32(hn & cols);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same recurrence arranged for what gfx950 issues at the full rate (v_and / v_or / v_add / v_bitop3; shifts by
+// v_add x, x; no v_alignbit, no left shift: bench_support/micro/op_cost.hip) -- 59 instead of 73 cycles of SIMD time per
+// column:
+//   * the pattern stays RIGHT-aligned (position j = bit j, planes as build_planes leaves them, no per-pair shift); rows at
+//     and above lp belong to the neighbour string or are zero and never influence the rows below them (carries and
+//     shifts only travel upwards);
+//   * no per-column history: the distance after exactly lt columns is lt + (vertical +1 deltas) - (vertical -1 deltas)
+//     over the lp pattern rows of THAT column, so each lane keeps a copy of (Pv, Mv) from the column where its own text
+//     ends; a wave only pays for that (a compare and two bit-selects) in the columns tmin .. tmax where some lane ends;
+//   * ~HP is carried instead of HP: (HP << 1) | 1 = ~(~HP + ~HP), which folds into the two v_bitop3 that consume it.
+// lt, lp >= 1; tmin <= lt <= tmax, both lane-uniform.
+// ---------------------------------------------------------------------------------------------
+// x + x as an add the compiler cannot turn back into a shift (v_lshlrev_b32 costs two issue slots on gfx950, v_add_u32 one)
+STRSIM_HD uint32_t twice(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x + x;
+#endif
+}
+
+template <int NP>
+STRSIM_HD uint32_t lev_myers32_snap(const uint32_t (&wt)[8], uint32_t lt, uint32_t tmin, uint32_t tmax, const uint32_t (&P)[NP],
+                                    uint32_t lp)
+{
+    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u, sP = 0u, sM = 0u;
+#pragma unroll
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
+        // one straight-line block per group of columns (the match masks of the whole group are independent work the
+        // scheduler can put between the dependent steps of the recurrence), the copies behind it under one uniform test
+        uint32_t Pc[COLS_PER_TEST], Mc[COLS_PER_TEST];
+#pragma unroll
+        for (int jj = 0; jj < COLS_PER_TEST; ++jj) {
+            const int j = COLS_PER_TEST * g + jj;
+            const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wt[j >> 2], j & 3);
+            const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
+            const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
+            const uint32_t nX = twice(nHP);                                 // ~((HP << 1) | 1)
+            const uint32_t HN2 = twice(D0 & Pv);                            // HN << 1
+            Pv = bitop3<0xF2>(HN2, D0, nX);                                 // (HN << 1) | ~(D0 | X)
+            Mv = bitop3<0x50>(D0, D0, nX);                                  // D0 & X
+            Pc[jj] = Pv;
+            Mc[jj] = Mv;
+        }
+        if ((uint32_t)(COLS_PER_TEST * (g + 1)) >= tmin) {                 // (uniform) some lane's text may end in this group
+#pragma unroll
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj) {
+                const uint32_t here = lt == (uint32_t)(COLS_PER_TEST * g + jj + 1) ? 0xFFFFFFFFu : 0u;
+                sP = bitop3<0xCA>(here, Pc[jj], sP);                        // here ? Pv : sP
+                sM = bitop3<0xCA>(here, Mc[jj], sM);
+            }
+        }
+    }
+    const uint32_t rows = low_ones(lp);
+    return lt + popc32(sP & rows) - popc32(sM & rows);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@
 #define STRSIM_STAGE_CAP 10240 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB)
 #endif
 #ifndef STRSIM_STAGE_WAVES_PER_EU
-#define STRSIM_STAGE_WAVES_PER_EU 4
+#define STRSIM_STAGE_WAVES_PER_EU 5
 #endif
 #ifndef STRSIM_STAGE_BUCKET_SHIFT
 #define STRSIM_STAGE_BUCKET_SHIFT 1
@@ -115,22 +115,19 @@ __device__ __forceinline__ void stage_lds32(const uint8_t *p, uint32_t (&w)[8])
     w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
 }
 
-// Levenshtein result as an index into the 33 x 33 table of 1 - dist/den (dist * 33 + den); 0xFFFF is never produced
+// Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
 template <int NP>
 __device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
-                                                   uint32_t tmax)
+                                                   uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
-    const uint32_t s = 32u - lb1;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) P[k] <<= s;
-    const uint32_t dist = lev_myers32<NP>(wa, la1, tmax, P, lb1);
-    uint32_t code = dist * 33u + (la1 > lb1 ? la1 : lb1);
-    // both empty: 1.0 = entry (0, 1); one side empty: 0.0 = entry (1, 1)   (strsim.rs:128, :160)
-    if (!live) code = (la == 0u && lb == 0u) ? 1u : 34u;
+    const uint32_t dist = lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    uint32_t code = dist * (uint32_t)QTAB_N + (la1 > lb1 ? la1 : lb1);
+    // both empty: 1.0 = 1 - 0/1; one side empty: 0.0 = 1 - 1/1   (strsim.rs:128, :160)
+    if (!live) code = (la == 0u && lb == 0u) ? 1u : (uint32_t)QTAB_N + 1u;
     return code;
 }
 
@@ -150,9 +147,12 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
     const uint32_t tmax = wave_max_rounded(la);
     const bool wide = __ballot(fast && (vary & 0x60u)) != 0ull; // six-plane rounds run as seven (register budget)
     if (MEASURE == LEVENSHTEIN) {
+        // the round's rows come in bucket order (two text lengths per bucket), so its first row bounds the shortest text
+        const uint32_t lt0 = uniform(lt);
+        const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
         uint32_t code;
-        if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmax);
-        else code = stage_lev_code<5>(wt, la, wp, lb, tmax);
+        if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmin, tmax);
+        else code = stage_lev_code<5>(wt, la, wp, lb, tmin, tmax);
         if (fast) s_code[idx] = (uint16_t)code;
     } else {
         double res;
@@ -180,19 +180,10 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     __shared__ uint2 s_desc[B];
     __shared__ uint16_t s_code[LEV ? B : 1];   // Levenshtein: table index per row, 0xFFFF = not computed here
     __shared__ double s_val[LEV ? 1 : B];      // other measures: the f64 result, all-ones = not computed here
-    __shared__ double s_levtab[LEV ? 33 * 33 : 1];
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
     if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
-    if (LEV) {
-        // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: the epilogue's own IEEE division
-        // (strsim.rs:160), done once per workgroup instead of once per pair
-        for (uint32_t i = tid; i < 33u * 33u; i += STAGE_BLOCK) {
-            const uint32_t d = i / 33u, m = i % 33u;
-            s_levtab[i] = m ? epilogue_levenshtein(d, m, m) : 0.0;
-        }
-    }
     if (tid < 32u) s_cnt[tid] = 0u;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
@@ -224,12 +215,12 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     // workgroups ran equally fast, but the SIMD serves its OLDEST wave first, so of the four workgroups resident on a CU
     // the first finishes its share at 57 % of the kernel's time and the last one runs alone at the end (measured: ends at
     // 1.15 / 1.40 / 1.70 / 2.01 ms of a 2.05 ms launch).  The size of a range shrinks with the work that is left
-    // (remaining / (2 x workgroups), between one block and 256 chunks), so all workgroups end within about a block.
+    // (remaining / (4 x workgroups), between one block and 64 chunks), so all workgroups end within about a block.
     const uint64_t nchunks = (n + 63u) >> 6;
     auto grab = [&](uint32_t seen, uint32_t &lo, uint32_t &sz) { // thread 0 only
         const uint64_t left = nchunks > seen ? nchunks - seen : 0u;
-        uint64_t want = left / (2u * (uint64_t)gridDim.x);
-        want = want < (uint64_t)(B / 64) ? (uint64_t)(B / 64) : (want > 256u ? 256u : want);
+        uint64_t want = left / (4u * (uint64_t)gridDim.x);
+        want = want < (uint64_t)(B / 64) ? (uint64_t)(B / 64) : (want > 64u ? 64u : want);
         sz = (uint32_t)want;
         lo = atomicAdd(&sched[0], sz);
     };
@@ -292,7 +283,10 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
                     const uint32_t code = s_code[i];
                     s_code[i] = 0xFFFFu;
                     undone = code == 0xFFFFu;
-                    v = s_levtab[undone ? 0u : code];
+                    // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
+                    // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
+                    // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
+                    v = 1.0 - qtab[undone ? 0u : code];
                 } else {
                     v = s_val[i];
                     reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;

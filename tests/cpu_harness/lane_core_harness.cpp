@@ -49,6 +49,26 @@ extern "C" double harness_lane_pair(int measure, const uint8_t *a, uint32_t la, 
     }
 }
 
+// the full-rate form of the Levenshtein core (right-aligned pattern, copies of the vertical deltas at the lane's own last
+// column): plain distance, text = a walked in tmax columns with lanes' ends expected from column tmin on
+extern "C" uint32_t harness_lev_snap(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, uint32_t tmin, uint32_t tmax,
+                                     int np, int fill)
+{
+    uint32_t wa[8], wb[8];
+    std::memset(wa, fill, sizeof wa);
+    std::memset(wb, fill, sizeof wb);
+    std::memcpy(wa, a, la);
+    std::memcpy(wb, b, lb);
+    if (np == 5) {
+        uint32_t P[5];
+        build_planes<5>(wb, P);
+        return lev_myers32_snap<5>(wa, la, tmin, tmax, P, lb);
+    }
+    uint32_t P[7];
+    build_planes<7>(wb, P);
+    return lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
+}
+
 // plane build vs the definition, for any 32 bytes
 extern "C" int harness_check_planes(const uint8_t *bytes32)
 {

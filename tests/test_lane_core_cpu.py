@@ -34,6 +34,8 @@ def harness():
     L.harness_lane_pair_wide.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_sym.restype = C.c_double
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
+    L.harness_lev_snap.restype = C.c_uint32
+    L.harness_lev_snap.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     L.harness_check_planes.restype = C.c_int
     L.harness_check_planes.argtypes = [C.c_char_p]
     return L
@@ -190,3 +192,42 @@ def test_symbol_cores_bit_exact(harness, measure, script):
                 assert bits(got) == bits(O.pair(measure, a, b)), (measure, a, b, got)
         eligible += ok
     assert eligible > 300 or script == "mixed"
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j - 1] + (ca != cb), prev[j] + 1, cur[j - 1] + 1))
+        prev = cur
+    return prev[-1]
+
+
+@pytest.mark.parametrize("np_,alphabet", [(5, "abcdefghijklmnopqrstuvwxyz"), (5, "ab"), (7, "aZ09 ~!bcXY")])
+def test_levenshtein_snapshot_core(harness, np_, alphabet):
+    """lev_myers32_snap (the full-rate arrangement the staged kernel runs) = the textbook distance (strsim.rs:141-160), for
+    every way a wave can run it: the lane's text may end anywhere in [tmin, tmax], bytes behind the strings are garbage."""
+    rng = random.Random(20 + np_)
+    fill = ord("q") if np_ == 5 else ord("#")
+    for _ in range(3000):
+        la, lb = rng.randint(1, 32), rng.randint(1, 32)
+        a = "".join(rng.choice(alphabet) for _ in range(la))
+        if rng.random() < 0.5:
+            b = list(a)
+            for _e in range(rng.randint(0, 3)):
+                k = rng.randrange(len(b) + 1)
+                r = rng.random()
+                if r < 0.34 and b:
+                    del b[min(k, len(b) - 1)]
+                elif r < 0.67:
+                    b.insert(k, rng.choice(alphabet))
+                elif b:
+                    b[min(k, len(b) - 1)] = rng.choice(alphabet)
+            b = "".join(b)[:32] or rng.choice(alphabet)
+        else:
+            b = "".join(rng.choice(alphabet) for _ in range(lb))
+        tmin = rng.randint(1, len(a))
+        tmax = min(32, (rng.randint(len(a), 32) + 1) & ~1)
+        got = harness.harness_lev_snap(a.encode(), len(a), b.encode(), len(b), tmin, max(tmax, len(a) + (len(a) & 1)), np_, fill)
+        assert got == _edit_distance(a, b), (a, b, tmin, tmax)
