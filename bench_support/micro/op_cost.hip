@@ -37,7 +37,20 @@
     X(28, "v_mul_u32_u24_e32 %0, %0, %1") \
     X(29, "v_lshlrev_b64 %3, 1, %3") \
     X(30, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf") \
-    X(31, "v_bitop3_b32 %0, %1, %2, %0 bitop3:0x96")
+    X(31, "v_bitop3_b32 %0, %1, %2, %0 bitop3:0x96") \
+    X(32, "v_ashrrev_i32_sdwa %0, %2, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1") \
+    X(33, "v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD") \
+    X(34, "v_cmp_eq_u32_e32 vcc, %0, %1") \
+    X(35, "v_cndmask_b32_e64 %0, %0, %1, s[2:3]") \
+    X(36, "v_min_u32_e32 %0, %0, %1") \
+    X(37, "v_or_b32_e32 %0, %0, %1") \
+    X(38, "v_subrev_u32_e32 %0, %0, %1") \
+    X(39, "v_lshrrev_b32_e32 %0, %1, %0") \
+    X(40, "v_lshlrev_b32_e32 %0, %1, %0") \
+    X(41, "v_lshlrev_b16_e32 %0, 1, %0") \
+    X(42, "v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") \
+    X(43, "v_readfirstlane_b32 s4, %0") \
+    X(44, "v_bfe_i32 %0, %1, 3, 1")
 
 template <int OP>
 __global__ __launch_bounds__(64) void k(uint32_t *out, unsigned long long *clk, uint32_t seed, int iters)
@@ -49,7 +62,7 @@ __global__ __launch_bounds__(64) void k(uint32_t *out, unsigned long long *clk, 
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int u = 0; u < 512; ++u) {
-#define X(ID, TXT) if (OP == ID) asm volatile(TXT : "+v"(x), "+v"(y), "+v"(z), "+v"(q));
+#define X(ID, TXT) if (OP == ID) asm volatile(TXT : "+v"(x), "+v"(y), "+v"(z), "+v"(q) : : "vcc", "s4", "s2", "s3");
             OPS(X)
 #undef X
         }
@@ -96,7 +109,7 @@ template <int OP>
 static void all()
 {
     run<OP>(8);
-    if constexpr (OP + 1 < 32) all<OP + 1>();
+    if constexpr (OP + 1 < 45) all<OP + 1>();
 }
 
 int main()

@@ -54,8 +54,7 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
-    int stage_wg_per_cu = 4;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pipe / k_lane_pairs instead of k_lane_stage (A/B runs)
-    int pipe_wg_per_cu = 5;   // STRSIM_PIPE_WG_PER_CU overrides; 0 = use k_lane_pairs instead of k_lane_pipe (A/B runs)
+    int stage_wg_per_cu = 5;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pairs instead of k_lane_stage (A/B runs)
     int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only)
@@ -224,10 +223,6 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         const int v = atoi(env);
         if (v >= 0 && v <= 64) c->stage_wg_per_cu = v;
     }
-    if (const char *env = getenv("STRSIM_PIPE_WG_PER_CU")) {
-        const int v = atoi(env);
-        if (v >= 0 && v <= 64) c->pipe_wg_per_cu = v;
-    }
     if (const char *env = getenv("STRSIM_LEV_WAVES_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 256) c->lev_waves_per_cu = v;
@@ -350,7 +345,6 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
-    la.pipe_grid = c->pipe_wg_per_cu > 0 ? c->num_cu * c->pipe_wg_per_cu : 0;
     la.wide_grid = c->num_cu * 3; // resident (LDS)
     {
         int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)

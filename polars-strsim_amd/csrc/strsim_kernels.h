@@ -53,7 +53,6 @@ struct LaunchArgs {
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     int stage_grid;               // > 0: k_lane_stage (bytes staged through LDS) with this many persistent workgroups
-    int pipe_grid;                // > 0: k_lane_pipe (persistent, software-pipelined) with this many workgroups instead of k_lane_pairs
     int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
     uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words

@@ -270,7 +270,6 @@ k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
     lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
 }
 
-#include "strsim_lane_pipe.h"
 #include "strsim_lane_stage.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1810,16 +1809,6 @@ static void launch_pair(const LaunchArgs &a)
         const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;
         hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab, a.sched);
-    } else if (a.pipe_grid > 0) {
-        // software-pipelined form (strsim_lane_pipe.h): persistent workgroups, one per resident slot
-        const uint64_t npb = (a.n + (PIPE_ROWS - 1)) / PIPE_ROWS;
-        const uint64_t gp = npb < (uint64_t)a.pipe_grid ? npb : (uint64_t)a.pipe_grid;
-        if (a.rowsA == 1 || a.rowsB == 1)
-            hipLaunchKernelGGL((k_lane_pipe<M, true>), dim3((unsigned)gp), dim3(PIPE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                               a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab);
-        else
-            hipLaunchKernelGGL((k_lane_pipe<M, false>), dim3((unsigned)gp), dim3(PIPE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                               a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab);
     } else {
         hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
@@ -1941,15 +1930,6 @@ hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, hi
 
 } // namespace strsim
 
-#ifdef STRSIM_PIPE_STAMPS
-// diagnostic build only: copies the per-wave phase cycle sums of the last k_lane_pipe launch to the host
-extern "C" __attribute__((visibility("default"))) int strsim_debug_pipe_stamps(unsigned long long *dst, size_t waves)
-{
-    if (waves > 16384) waves = 16384;
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(strsim::g_pipe_stamps), waves * 10 * sizeof(unsigned long long), 0,
-                                    hipMemcpyDeviceToHost);
-}
-#endif
 
 #ifdef STRSIM_STAGE_STAMPS
 // diagnostic build only: copies the per-wave phase cycle sums of the last k_lane_stage launch to the host

@@ -1,5 +1,5 @@
 // strsim_lane_common.h -- small device helpers shared by the one-pair-per-lane kernels (strsim_kernels.hip,
-// strsim_lane_pipe.h).  gfx950 only.
+// strsim_lane_stage.h).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -65,7 +65,7 @@ constexpr int STAGE_DMA_ITERS = (STAGE_CAP + 16 * STAGE_BLOCK - 1) / (16 * STAGE
 constexpr int STAGE_BSH = STRSIM_STAGE_BUCKET_SHIFT;  // buckets of 2^BSH column counts
 constexpr int STAGE_NBK = (32 >> STAGE_BSH) + 1;      // + one for the rows this kernel leaves to the later ones
 static_assert(STAGE_RPT >= 1 && STAGE_RPT <= 4 && STAGE_RPW >= 1, "STAGE_ROWS is 256, 512 or 1024");
-static_assert(STAGE_CAP % 1024 == 0 && 2 * STAGE_COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
+static_assert(STAGE_CAP % 16 == 0 && 2 * STAGE_COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
 static_assert(STAGE_NBK <= 32, "the bucket scan runs on 32 lanes");
 
 // LDS byte address of a __shared__ object (what M0 / a DS instruction's address operand hold)
@@ -76,20 +76,21 @@ static_assert(STAGE_NBK <= 32, "the bucket scan runs on 32 lanes");
 // s_waitcnt vmcnt(0) (it cannot tell the arrays apart), which would serialise exactly the overlap this kernel is built for.
 // The kernel waits for its DMAs itself: s_waitcnt vmcnt(0) + workgroup barrier before the first read of the data.
 // M0 (the LDS base of the DMA) is saved and restored inside the statement; s_nop 0: SALU write of M0 -> LDS-DMA read.
-__device__ __forceinline__ void lds_dma_b128(const void *gsrc, uint32_t lds_dst)
+// (address = uniform base + a 32-bit byte offset per lane: no 64-bit vector arithmetic)
+__device__ __forceinline__ void lds_dma_b128(const void *gbase, uint32_t goff, uint32_t lds_dst)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(goff), "s"(gbase), "s"(lds_dst)
                  : "memory");
 }
-__device__ __forceinline__ void lds_dma_b32(const void *gsrc, uint32_t lds_dst)
+__device__ __forceinline__ void lds_dma_b32(const void *gbase, uint32_t goff, uint32_t lds_dst)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
+                 : "v"(goff), "s"(gbase), "s"(lds_dst)
                  : "memory");
 }
 
@@ -113,6 +114,18 @@ __device__ __forceinline__ void stage_lds32(const uint8_t *p, uint32_t (&w)[8])
     const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
     w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
     w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+}
+
+// inclusive prefix sum over lanes 0..31 (and, independently, 32..63) with five DPP adds: shifts by 1, 2, 4, 8 inside the
+// rows of 16 lanes (lanes shifted in from outside a row read 0), then lane 15 of the even rows added to the odd rows
+__device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true); // row_bcast:15 into rows 1 and 3
+    return x;
 }
 
 // Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
@@ -174,7 +187,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
-    __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 64]; // offsets of the rows from the next block's start on
+    __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 4]; // offsets of the rows from the next block's start on
     __shared__ uint32_t s_cnt[32];
     __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
     __shared__ uint2 s_desc[B];
@@ -217,12 +230,14 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     // 1.15 / 1.40 / 1.70 / 2.01 ms of a 2.05 ms launch).  The size of a range shrinks with the work that is left
     // (remaining / (4 x workgroups), between one block and 64 chunks), so all workgroups end within about a block.
     const uint64_t nchunks = (n + 63u) >> 6;
+    const uint32_t nchunks32 = (uint32_t)nchunks; // (at most 2^32 - 1 rows per call)
     auto grab = [&](uint32_t seen, uint32_t &lo, uint32_t &sz) { // thread 0 only
-        const uint64_t left = nchunks > seen ? nchunks - seen : 0u;
-        uint64_t want = left / (4u * (uint64_t)gridDim.x);
-        want = want < (uint64_t)(B / 64) ? (uint64_t)(B / 64) : (want > 64u ? 64u : want);
-        sz = (uint32_t)want;
-        lo = atomicAdd(&sched[0], sz);
+        // (64 * 4 * workgroups chunks left or more: the cap; no division on this path)
+        const uint32_t left = nchunks32 > seen ? nchunks32 - seen : 0u;
+        uint32_t want = 64u;
+        if (left < 256u * gridDim.x) want = left / (4u * gridDim.x);
+        sz = want < (uint32_t)(B / 64) ? (uint32_t)(B / 64) : want;
+        lo = __hip_atomic_fetch_add(&sched[0], sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     uint32_t grab_lo = 0u, grab_sz = 0u; // thread 0: the range after the next one, on its way
     if (tid == 0u) {
@@ -247,19 +262,20 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     const uint32_t wvu = uniform(wv);
     // offsets DMA: the offsets of rows row .. row + min(B, row_end - row) (one more than rows) of each column side that
     // is not a literal -> s_off[side][0 ..]
+    const uint32_t tid4 = tid * 4u, tid16 = tid * 16u;
     auto dma_offsets = [&](uint64_t row) {
         const uint32_t cnt = (uint32_t)(row_end - row < (uint64_t)B ? row_end - row : (uint64_t)B); // rows available
+        const uint32_t *const pa = offA + row, *const pb = offB + row;
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
-            const uint32_t c = (uint32_t)it * STAGE_BLOCK + tid;
-            if (c <= cnt) {
-                if (!bcastA) lds_dma_b32(offA + row + c, ldsOffA + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
-                if (!bcastB) lds_dma_b32(offB + row + c, ldsOffB + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+            if (tid + (uint32_t)it * STAGE_BLOCK <= cnt) {
+                if (!bcastA) lds_dma_b32(pa + it * STAGE_BLOCK, tid4, ldsOffA + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                if (!bcastB) lds_dma_b32(pb + it * STAGE_BLOCK, tid4, ldsOffB + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
             }
         }
         if (tid == 0u && cnt == (uint32_t)B) { // the offset behind the last row of a full block
-            if (!bcastA) lds_dma_b32(offA + row + B, ldsOffA + 4u * (uint32_t)B);
-            if (!bcastB) lds_dma_b32(offB + row + B, ldsOffB + 4u * (uint32_t)B);
+            if (!bcastA) lds_dma_b32(pa + B, tid4, ldsOffA + 4u * (uint32_t)B);
+            if (!bcastB) lds_dma_b32(pb + B, tid4, ldsOffB + 4u * (uint32_t)B);
         }
     };
 
@@ -315,7 +331,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         }
         // ---- the block: as many of the next 64-row chunks (at most B / 64) as have their bytes inside the staging areas
         const uint32_t avail = (uint32_t)(row_end - row0 < (uint64_t)B ? row_end - row0 : (uint64_t)B); // rows whose offsets are in s_off
-        const uint32_t baseA = bcastA ? litA0 : s_off[0][0], baseB = bcastB ? litB0 : s_off[1][0];
+        const uint32_t baseA = bcastA ? litA0 : uniform(s_off[0][0]), baseB = bcastB ? litB0 : uniform(s_off[1][0]);
         const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(valA + baseA) & 15u);
         const uint32_t misB = (uint32_t)(reinterpret_cast<uintptr_t>(valB + baseB) & 15u);
         uint32_t rows;
@@ -329,7 +345,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
             // chunks 0 .. k-1 fit: k = number of trailing ones; at least one chunk is taken even if it overflows
             uint32_t k = (uint32_t)__builtin_ctzll(~okm);
             if (k == 0u) k = 1u;
-            rows = k * 64u < avail ? k * 64u : avail;
+            rows = uniform(k * 64u < avail ? k * 64u : avail);
         }
         const uint32_t endA = bcastA ? baseA : uniform(s_off[0][rows]), endB = bcastB ? baseB : uniform(s_off[1][rows]);
         // ---- A: bytes DMA(j).  Column side X: the 16-byte chunks from the aligned address below the block's first byte
@@ -341,9 +357,10 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
             const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
 #pragma unroll
             for (int it = 0; it < STAGE_DMA_ITERS; ++it) {
-                const uint32_t c = (uint32_t)it * STAGE_BLOCK + tid;
-                if (c < chunksA) lds_dma_b128(gA + 16u * c, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
-                if (c < chunksB) lds_dma_b128(gB + 16u * c, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                if (tid + (uint32_t)it * STAGE_BLOCK < chunksA)
+                    lds_dma_b128(gA + 16 * it * STAGE_BLOCK, tid16, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                if (tid + (uint32_t)it * STAGE_BLOCK < chunksB)
+                    lds_dma_b128(gB + 16 * it * STAGE_BLOCK, tid16, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
             }
         }
         STAGE_STAMP(0);
@@ -381,13 +398,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         uint32_t nmine;
         {
             const uint32_t c = s_cnt[lane & 31u];
-            uint32_t inc = c;
-#pragma unroll
-            for (int sft = 1; sft < 32; sft <<= 1) {
-                const uint32_t up = __shfl_up(inc, sft, 32);
-                if ((lane & 31u) >= (uint32_t)sft) inc += up;
-            }
-            const uint32_t exc = inc - c;
+            const uint32_t exc = scan32_inclusive(c) - c;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const uint32_t base = __shfl(exc, skey[q], 32);
