@@ -4,9 +4,10 @@
 One step = one pass of the hot path (lane-per-pair kernel + wave-per-pair kernel) over one rank's
 shard of a synthetic two-column Utf8 frame that is already resident in HBM.  Default workload =
 BASELINE.json configs[1]: Levenshtein, 100 M rows, <= 32-byte strings, one MI355X.  With N > 1 ranks
-(launched by torch.distributed.run, one process per GPU) every rank holds its own 100 M-row shard of an
-N x 100 M-row frame (weak scaling) and each step's f64 shard is gathered to rank 0 over RCCL/xGMI on a
-side stream, overlapped with the next step's kernels.
+(launched by torch.distributed.run, one process per GPU) the SAME frame is cut by the reference's row partition
+(split_offsets(rows, N), strsim.rs:21-39: rows / N each, remainder to the last rank) -- strong scaling, the metric
+BASELINE.json names ("100 M rows @ 1/2/4/8 GPU") -- and each step's f64 shard is gathered to rank 0 over RCCL/xGMI on a
+side stream, overlapped with the next step's kernels.  --scaling weak holds the config's row count per GPU instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      -- dominant kernel (k_lane_pairs) vs the HBM roof, from hipEvents on its own stream
@@ -34,7 +35,10 @@ def parse():
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--config", default="cfg2", help="cfg1|cfg2|cfg3|cfg5 (BASELINE.json configs; cfg2 = headline)")
-    p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's row count)")
+    p.add_argument("--rows", type=int, default=0, help="rows of the frame (strong) / per GPU (weak); default: the config's row count")
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                   help="N>1: strong = the config's frame split over the ranks (BASELINE metric); weak = the config's row count per rank")
+    p.add_argument("--force-codec", action="store_true", help="testing only: code the gathered column even when strings may exceed 32 bytes")
     p.add_argument("--measure", default="", help="override the config's measure")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the result shards")
     p.add_argument("--no-codec", action="store_true", help="N>1: gather raw f64 instead of 16-bit codes")
@@ -52,7 +56,15 @@ def cpu_baseline(measure, cfg, rows_total):
     import oracle_lib as O
     from bench_support import workload as W
     _, _, law, lo, hi, seed = cfg
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    cores, quota_note = logical, ""
+    try:  # a cgroup CPU quota (the GPU boxes: 16 CPUs' worth of 256 logical) is what this process can really use:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # more threads than that only get throttled
+        if q != "max":
+            cores = max(1, min(logical, int(round(int(q) / int(per)))))
+            quota_note = f", cgroup CPU quota {int(q) / int(per):g} of {logical} logical CPUs"
+    except Exception:
+        pass
     n = 250_000 * max(1, min(cores, 64) // 4)
     best = None
     while True:
@@ -68,7 +80,7 @@ def cpu_baseline(measure, cfg, rows_total):
     n, dt, out = best
     return {"value": n / dt / 1e6, "unit": "M string-pairs/s", "cores": cores, "kind": "port",
             "sample": f"first {n} rows of the same synthetic frame, {dt:.1f} s wall, oracle/strsim_oracle.c on {cores} threads "
-                      f"(split_offsets partition)"}, (n, out)
+                      f"(split_offsets partition){quota_note}"}, (n, out)
 
 
 def plugin_e2e(measure, cfg, rows):
@@ -105,6 +117,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit(f"--gpus {a.gpus} needs one process per GPU: python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if a.same_device:
@@ -121,11 +135,18 @@ def main():
     cfg = W.CONFIGS[a.config]
     measure = a.measure or cfg[0]
     measures = list(S.MEASURES) if measure == "all" else [measure]  # cfg4: five passes over the same frame per step
-    rows = a.rows or cfg[1]
     _, _, law, lo, hi, seed = cfg
+    # the frame and this rank's shard of it
+    if a.scaling == "weak":
+        total_rows = (a.rows or cfg[1]) * world
+        shards = [(r * (total_rows // world), total_rows // world) for r in range(world)]
+    else:
+        total_rows = a.rows or cfg[1]
+        shards = S.split_offsets(total_rows, world)  # strsim.rs:21-39
+    row_base, rows = shards[rank]
 
-    # rank r holds rows [r*rows, (r+1)*rows) of the (world*rows)-row frame; a shard whose packed values would not fit
-    # 32-bit offsets (cfg5: ~5 GB per column) is held as several row batches, each its own offsets+values pair
+    # a shard whose packed values would not fit 32-bit offsets (cfg5: ~5 GB per column) is held as several row batches,
+    # each its own offsets+values pair
     mean_len = (lo + hi) / 2.0 if law == W.UNIFORM else 26.0
     nparts = max(1, int(rows * mean_len * 1.15 / 3.5e9) + (1 if rows * mean_len * 1.15 > 3.5e9 else 0))
     bounds = [rows * p // nparts for p in range(nparts + 1)]
@@ -133,7 +154,7 @@ def main():
     bytesA = bytesB = 0
     for p in range(nparts):
         r0, r1 = bounds[p], bounds[p + 1]
-        oa, va, ob, vb, ba, bb = W.device_columns(seed, law, lo, hi, rank * rows + r0, r1 - r0, dev)
+        oa, va, ob, vb, ba, bb = W.device_columns(seed, law, lo, hi, row_base + r0, r1 - r0, dev)
         parts.append((r0, r1, oa, va, ob, vb))
         bytesA += ba
         bytesB += bb
@@ -152,8 +173,8 @@ def main():
         ok = 1
         try:
             # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
-            shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend,
-                                    codec_chars=32 if (hi <= 32 and not a.no_codec) else None)
+            shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend, parts=shards,
+                                    codec_chars=32 if ((hi <= 32 or a.force_codec) and not a.no_codec) else None)
             # preflight, outside any timing: one tiny gather over the same call path builds the communicator (so that it is
             # not built inside the timed region when --warmup is 0) and shows whether this backend can gather at all
             probe = torch.zeros(64, dtype=torch.uint8, device="cpu" if shipper.host else dev)
@@ -224,14 +245,16 @@ def main():
             sums = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(sums, mine)
             if rank == 0:
-                got = shipper.recv if not (shipper.host and not shipper.codecs) else shipper.recv_host.to(dev)
-                gather_ok = all(int(got[r * rows:(r + 1) * rows].view(torch.int64).sum().item()) == int(sums[r].item())
-                                for r in range(world))
+                got = shipper.result()
+                gather_ok = all(int(got[o:o + ln].view(torch.int64).sum().item()) == int(sums[r].item())
+                                for r, (o, ln) in enumerate(shards))
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = world * rows * a.steps / dt / 1e6
-        read_bytes = bytesA + bytesB + 2 * 4 * (rows + nparts)   # each byte/offset counted once
+        value = total_rows * a.steps / dt / 1e6
+        # each byte/offset counted once; per launch of the dominant kernel on THIS rank's shard (the
+        # roofline object describes one GPU's kernel, `value` the whole job)
+        read_bytes = bytesA + bytesB + 2 * 4 * (rows + nparts)
         write_bytes = 8 * rows
         lane_ms = tm["lane_ms"] / max(tm["lane_launches"], 1) * nparts   # per pass over the whole shard
         wave_ms = tm["wave_ms"] / max(tm["wave_launches"], 1) * nparts
@@ -239,28 +262,33 @@ def main():
         # (bench_support/profile.sh -> profiles/traffic.json; FETCH_SIZE doubled per the gfx950 note)
         traffic = None
         try:
+            import hashlib
+            from strsim_amd import _lib as L_
+            lib_sha = hashlib.sha256(open(L_.LIB_PATH, "rb").read()).hexdigest()[:16]
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             key = f"{a.config}:{measures[0]}:{rows}"
-            if len(measures) == 1 and key in tj:
+            # only a counter run of THIS build counts (bench_support/profile.sh records the library's hash with the figure)
+            if len(measures) == 1 and key in tj and tj[key].get("lib_sha256") == lib_sha:
                 traffic = tj[key]["traffic_bytes_per_launch"] * nparts  # per pass over the whole shard, like `achieved`
         except Exception:
             pass
         # the dominant kernel: k_lane_pairs, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
         # k_wave_pairs, timed together by the second event pair) takes longer -- cfg3 and cfg5
-        dom_ms, dom_name = lane_ms, "k_lane_pairs<%s>" % measures[0]
+        dom_ms, dom_name = lane_ms, ("k_lane_stage<%s>" if len(measures) == 1 else "k_lane_pairs_all (five outputs)%s") % (measures[0] if len(measures) == 1 else "")
         if wave_ms > lane_ms:
             dom_ms = wave_ms
             dom_name = ("k_wave_pairs<%s>" if (a.config == "cfg5" or hi > 128) else "k_lane_wide<%s> (+ k_lane_utf8, k_wave_pairs)") % measures[0]
         achieved = read_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         res = {
-            "metric": "M string-pairs/s, %s, %d M rows/GPU (+ achieved HBM GB/s in roofline)" % (measure, rows // 1_000_000),
+            "metric": "M string-pairs/s, %s, %d M rows%s (+ achieved HBM GB/s in roofline)" %
+                      (measure, (total_rows if a.scaling == "strong" else rows) // 1_000_000, " per GPU" if a.scaling == "weak" else ""),
             "passes_per_step": len(measures),
             "value": value, "unit": "M string-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "u8/u32 bit-parallel, f64 epilogue", "data": "synthetic",
-            "config": {"workload": f"{a.config}: {measure}, {rows} rows per GPU, lengths "
+            "config": {"workload": f"{a.config}: {measure}, {total_rows} rows ({a.scaling} scaling: {rows} on rank 0), lengths "
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
-                       "rows_per_gpu": rows, "gather_f64_to_rank0": bool(gather),
+                       "rows_total": total_rows, "rows_rank0": rows, "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
                        "gather_verified": gather_ok, "gather_note": gather_note,

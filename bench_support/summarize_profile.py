@@ -32,9 +32,14 @@ def traffic_json(out, key, kernel="k_lane_pairs"):
         if not v:
             return
         vals[ctr] = sum(v) / len(v)
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.environ.get("STRSIM_AMD_LIB") or os.path.join(root, "polars-strsim_amd", "polars_strsim", "libpolars_strsim_amd.so")
     rec = {"fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
            "traffic_bytes_per_launch": int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
-           "kernel": kernel, "source": os.path.basename(out)}
+           "kernel": kernel, "source": os.path.basename(out),
+           # bench.py prints the figure only for the build it was measured on
+           "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]}
     json.dump({key: rec}, open(os.path.join(out, "traffic_record.json"), "w"), indent=1)  # travels back in gpurun_out/
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
     try:

@@ -180,6 +180,13 @@ STRSIM_API int strsim_codec_decode_packed(strsim_ctx_t *ctx, const strsim_codec_
 STRSIM_API int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_rows,
                                   const double *exc_vals, uint32_t count);
 
+/* The same with the count read on the device: exc_count / exc_rows / exc_vals are another rank's exception block as it
+ * arrived with the gathered codes (strsim_amd/distributed.py).  A count above exc_cap (the sender had more exceptions than
+ * the block holds: the column is incomplete) increments *overflow (device memory). */
+STRSIM_API int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_count,
+                                           const uint32_t *exc_rows, const double *exc_vals, uint32_t exc_cap,
+                                           uint32_t *overflow);
+
 #define STRSIM_LANE_PATH_MAX_BYTES 32u   /* lane-per-pair kernels: both strings <= 32 bytes, ASCII */
 #define STRSIM_WAVE_PATH_MAX_BYTES 1024u /* wave-per-pair kernels: both strings <= 1024 bytes, any UTF-8 */
 

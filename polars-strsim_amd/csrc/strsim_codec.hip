@@ -198,6 +198,19 @@ __global__ void k_patch(double *__restrict__ out, const uint32_t *__restrict__ r
         out[row_base + rows[i]] = vals[i];
 }
 
+// the same patch with the count read on the device (the shipped exception block of another rank: nothing about it is known
+// on the host without a synchronisation); more exceptions than the block could hold -> *overflow is incremented
+__global__ void k_patch_indirect(double *__restrict__ out, uint64_t row_base, const uint32_t *__restrict__ count_ptr,
+                                 const uint32_t *__restrict__ rows, const double *__restrict__ vals, uint32_t cap,
+                                 uint32_t *__restrict__ overflow)
+{
+    const uint32_t count = *count_ptr;
+    if (count > cap && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1u);
+    const uint32_t n = count < cap ? count : cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[row_base + rows[i]] = vals[i];
+}
+
 #define HIP_TRY(expr)                                          \
     do {                                                       \
         hipError_t e__ = (expr);                               \
@@ -302,6 +315,16 @@ int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_base, const 
     if (count == 0) return STRSIM_OK;
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
     hipLaunchKernelGGL(k_patch, dim3(grid_for(count)), dim3(256), 0, st, out, exc_rows, exc_vals, count, row_base);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_count,
+                                const uint32_t *exc_rows, const double *exc_vals, uint32_t exc_cap, uint32_t *overflow)
+{
+    if (!ctx || !out || !exc_count || !exc_rows || !exc_vals || !overflow) { set_error("strsim_codec_patch_indirect: NULL argument"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    hipLaunchKernelGGL(k_patch_indirect, dim3(32), dim3(256), 0, st, out, row_base, exc_count, exc_rows, exc_vals, exc_cap, overflow);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

@@ -153,15 +153,22 @@ class Codec:
         except Exception:
             pass
 
-    def encode(self, vals, codes=None, ctx=None):
+    def _exc(self, exc):
+        """(count ptr, rows ptr, vals ptr, cap) of an exception block: this codec's own, or `exc` = (count, rows, vals)
+        tensors of the caller (e.g. views into a buffer that is shipped together with the codes)."""
+        if exc is None:
+            return self.exc_count.data_ptr(), self.exc_rows.data_ptr(), self.exc_vals.data_ptr(), self.EXC_CAP
+        cnt, rows, vals = exc
+        return cnt.data_ptr(), rows.data_ptr(), vals.data_ptr(), min(rows.numel(), vals.numel())
+
+    def encode(self, vals, codes=None, ctx=None, exc=None):
         """f64 tensor -> int16 tensor of codes (0xFFFF = exception, see exc_*); asynchronous on ctx's stream."""
         import torch
         ctx = ctx or self.ctx
         if codes is None:
             codes = torch.empty(vals.numel(), dtype=torch.int16, device=vals.device)
-        check(lib().strsim_codec_encode(ctx._h, self._h, vals.data_ptr(), vals.numel(), codes.data_ptr(),
-                                        self.exc_count.data_ptr(), self.exc_rows.data_ptr(), self.exc_vals.data_ptr(),
-                                        self.EXC_CAP))
+        pc, pr, pv, cap = self._exc(exc)
+        check(lib().strsim_codec_encode(ctx._h, self._h, vals.data_ptr(), vals.numel(), codes.data_ptr(), pc, pr, pv, cap))
         return codes
 
     def decode(self, codes, out=None, ctx=None):
@@ -180,15 +187,14 @@ class Codec:
     def packed_words(self, n):
         return int(lib().strsim_codec_packed_words(self._h, int(n)))
 
-    def encode_packed(self, vals, words=None, ctx=None):
+    def encode_packed(self, vals, words=None, ctx=None, exc=None):
         """f64 tensor -> int64 tensor of packed_words(n) words, 64 // bits codes each; asynchronous on ctx's stream."""
         import torch
         ctx = ctx or self.ctx
         if words is None:
             words = torch.empty(self.packed_words(vals.numel()), dtype=torch.int64, device=vals.device)
-        check(lib().strsim_codec_encode_packed(ctx._h, self._h, vals.data_ptr(), vals.numel(), words.data_ptr(),
-                                               self.exc_count.data_ptr(), self.exc_rows.data_ptr(), self.exc_vals.data_ptr(),
-                                               self.EXC_CAP))
+        pc, pr, pv, cap = self._exc(exc)
+        check(lib().strsim_codec_encode_packed(ctx._h, self._h, vals.data_ptr(), vals.numel(), words.data_ptr(), pc, pr, pv, cap))
         return words
 
     def decode_packed(self, words, n, out=None, ctx=None):
@@ -198,6 +204,15 @@ class Codec:
             out = torch.empty(int(n), dtype=torch.float64, device=words.device)
         check(lib().strsim_codec_decode_packed(ctx._h, self._h, words.data_ptr(), int(n), out.data_ptr()))
         return out
+
+    def patch_indirect(self, out, row_base, exc, overflow, ctx=None):
+        """out[row_base + rows[i]] = vals[i] for i < min(count, cap), the count read on the device; `exc` = (count, rows, vals)
+        tensors (an exception block as it arrived from another rank), `overflow`: int32 device tensor, incremented when
+        count > cap."""
+        ctx = ctx or self.ctx
+        cnt, rows, vals = exc
+        check(lib().strsim_codec_patch_indirect(ctx._h, out.data_ptr(), int(row_base), cnt.data_ptr(), rows.data_ptr(),
+                                                vals.data_ptr(), min(rows.numel(), vals.numel()), overflow.data_ptr()))
 
     def patch(self, out, row_base, exc_rows, exc_vals, count, ctx=None):
         ctx = ctx or self.ctx

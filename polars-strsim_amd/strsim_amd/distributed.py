@@ -56,19 +56,32 @@ def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=
 class ShardGatherer:
     """Ships every step's result shard(s) to rank 0 on a side stream, overlapped with the next step's kernels.
 
-    Transport is the raw f64 column, or -- when a Codec covers the measure (strings <= `codec_chars` characters) --
-    its lossless 16-bit code column, which rank 0 decodes back to f64 on the same side stream: 4x fewer bytes on the
-    one xGMI link each peer has into the root.  backend "nccl" (= RCCL) gathers device tensors; any other backend
-    stages through the host (only meant to smoke-test the control flow on one GPU).
+    Shards follow the reference's row partition (`parts` = split_offsets(total rows, world), strsim.rs:21-39), so the last
+    one may be longer; every rank ships the same number of bytes (the longest shard's), the root keeps each rank's own
+    length.  Transport is the raw f64 column, or -- when a Codec covers the measure (strings <= `codec_chars`
+    characters) -- its lossless code column, which rank 0 decodes back to f64 on a second side stream: 4x..7x fewer
+    bytes on the one xGMI link each peer has into the root.  Values outside the codec's table (rows with longer strings)
+    travel in an EXCEPTION BLOCK behind the codes -- count, rows, values, `exc_ship` entries -- and are patched in on the
+    root with the count read on the device; a rank with more exceptions than the block holds makes `drain()` raise
+    (nothing is ever left stale silently).  backend "nccl" (= RCCL) gathers device tensors; any other backend stages
+    through the host (only meant to smoke-test the control flow on one GPU).
     """
 
-    def __init__(self, ctx, compute_stream, measures, rows, device, backend="nccl", codec_chars=None):
-        """`compute_stream`: the torch stream whose handle `ctx` was created with (the kernels' stream)."""
+    def __init__(self, ctx, compute_stream, measures, rows, device, backend="nccl", codec_chars=None, parts=None,
+                 exc_ship=65536):
+        """`compute_stream`: the torch stream whose handle `ctx` was created with (the kernels' stream).
+        `rows`: this rank's shard length when `parts` is None (every rank the same), else ignored."""
         import strsim_amd as S
         if ctx.stream != compute_stream.cuda_stream:
             raise ValueError("ShardGatherer: ctx does not enqueue on compute_stream")
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.rows, self.dev, self.host = rows, device, backend != "nccl"
+        self.parts = list(parts) if parts is not None else [(r * rows, rows) for r in range(self.world)]
+        if len(self.parts) != self.world:
+            raise ValueError("ShardGatherer: one (offset, len) per rank")
+        self.rows = self.parts[self.rank][1]
+        self.cap_rows = max(p[1] for p in self.parts)
+        self.total = sum(p[1] for p in self.parts)
+        self.dev, self.host = device, backend != "nccl"
         self.compute = compute_stream
         self.comm = torch.cuda.Stream()    # encode + gather
         self.decode = torch.cuda.Stream()  # root only: decode of step i overlaps the gather of step i+1
@@ -85,20 +98,34 @@ class ShardGatherer:
                     self.codecs = {}
                     break
         self.codes, self.done = {}, {}
-        n = self.world * rows
         root = self.rank == 0
-        self.recv = torch.empty(n, dtype=torch.float64, device=device) if root else None
+        self.recv = torch.empty(self.total, dtype=torch.float64, device=device) if root else None
         self.recv_codes = None
         self.decoded = [None, None]
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # root: exception blocks that did not hold everything
         # bytes one rank ships per column: packed codes (64 // bits per 64-bit word) when that beats 16 bits per row
         self.packed = bool(self.codecs) and all(64 // c.bits > 4 for c in self.codecs.values())
         if self.codecs:
-            self.ship_bytes = max(8 * c.packed_words(rows) for c in self.codecs.values()) if self.packed else 2 * rows
+            code_bytes = max(8 * c.packed_words(self.cap_rows) for c in self.codecs.values()) if self.packed else 2 * self.cap_rows
+            self.code_bytes = (code_bytes + 15) & ~15
+            self.exc_ship = int(exc_ship)
+            self.ship_bytes = self.code_bytes + 16 + 12 * self.exc_ship  # codes | count (16 B) | rows u32 | values f64
         if self.codecs and root:  # codes travel as bytes: neither RCCL nor gloo has a 16-bit integer type
             self.recv_codes = [torch.empty(self.world * self.ship_bytes, dtype=torch.uint8, device="cpu" if self.host else device)
                                for _ in range(2)]
         elif root and self.host:
-            self.recv_host = torch.empty(n, dtype=torch.float64)
+            self.recv_host = torch.empty(self.world * self.cap_rows, dtype=torch.float64)
+        if not self.codecs and root and not self.host:
+            self.recv_pad = torch.empty(self.world * self.cap_rows, dtype=torch.float64, device=device) \
+                if any(p[1] != self.cap_rows for p in self.parts) else None
+
+    def _exc_views(self, buf, base):
+        """(count, rows, values) views of the exception block that starts `base` bytes into the uint8 tensor `buf`."""
+        k = self.exc_ship
+        cnt = buf[base:base + 4].view(torch.int32)
+        rows = buf[base + 16:base + 16 + 4 * k].view(torch.int32)
+        vals = buf[base + 16 + 4 * k:base + 16 + 12 * k].view(torch.float64)
+        return cnt, rows, vals
 
     @property
     def transport(self):
@@ -113,54 +140,81 @@ class ShardGatherer:
             self.compute.wait_event(ev)
 
     def submit(self, slot, measure, out):
+        """`out`: this rank's f64 shard (parts[rank][1] rows) of `measure`, complete on the compute stream."""
         codec = self.codecs.get(measure)
-        src = out
+        if out.numel() != self.rows:
+            raise ValueError(f"rank {self.rank}: shard has {out.numel()} rows, expected {self.rows}")
         self.comm.wait_stream(self.compute)
         with torch.cuda.stream(self.comm):
             if codec is not None:
                 buf = self.codes.get(slot)
                 if buf is None:
-                    buf = self.codes[slot] = torch.empty(self.ship_bytes, dtype=torch.uint8, device=self.dev)
-                # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's
-                # VALU-bound kernels
+                    buf = self.codes[slot] = torch.zeros(self.ship_bytes, dtype=torch.uint8, device=self.dev)
+                exc = self._exc_views(buf, self.code_bytes)
+                # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's kernels
                 if self.packed:
-                    codec.encode_packed(out, buf.view(torch.int64), ctx=self.ctx_comm)
+                    codec.encode_packed(out, buf[:self.code_bytes].view(torch.int64), ctx=self.ctx_comm, exc=exc)
                 else:
-                    codec.encode(out, buf.view(torch.int16), ctx=self.ctx_comm)
-                raw = buf
+                    codec.encode(out, buf[:2 * self.rows].view(torch.int16), ctx=self.ctx_comm, exc=exc)
                 b = self.nsub & 1
                 self.nsub += 1
                 if self.rank == 0 and self.decoded[b] is not None:
                     self.comm.wait_event(self.decoded[b])  # the decode that last read this receive buffer
-                work, _ = gather_column(raw.cpu() if self.host else raw, self.world * self.ship_bytes, dst=0, async_op=True,
+                work, _ = gather_column(buf.cpu() if self.host else buf, self.world * self.ship_bytes, dst=0, async_op=True,
                                         recv_buffer=self.recv_codes[b] if self.rank == 0 else None)
                 work.wait()
                 if self.rank == 0:
                     self.decode.wait_stream(self.comm)
                     with torch.cuda.stream(self.decode):
                         rc = self.recv_codes[b].to(self.dev) if self.host else self.recv_codes[b]
-                        if self.packed:  # every rank packed its own shard: decode them one by one
-                            for r in range(self.world):
-                                seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes].view(torch.int64)
-                                codec.decode_packed(seg, self.rows, self.recv[r * self.rows:(r + 1) * self.rows], ctx=self.ctx_decode)
-                        else:
-                            codec.decode(rc.view(torch.int16), self.recv, ctx=self.ctx_decode)
+                        for r, (off, ln) in enumerate(self.parts):  # every rank coded its own shard: decode them one by one
+                            seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes]
+                            dst = self.recv[off:off + ln]
+                            if self.packed:
+                                codec.decode_packed(seg[:self.code_bytes].view(torch.int64), ln, dst, ctx=self.ctx_decode)
+                            else:
+                                codec.decode(seg[:2 * ln].view(torch.int16), dst, ctx=self.ctx_decode)
+                            codec.patch_indirect(self.recv, off, self._exc_views(seg, self.code_bytes), self.overflow,
+                                                 ctx=self.ctx_decode)
                         self.decoded[b] = torch.cuda.Event()
                         self.decoded[b].record(self.decode)
             else:
-                work, _ = gather_column(src.cpu() if self.host else src, self.world * self.rows, dst=0, async_op=True,
-                                        recv_buffer=(self.recv_host if self.host else self.recv) if self.rank == 0 else None)
+                ragged = any(p[1] != self.cap_rows for p in self.parts)
+                src = out.cpu() if self.host else out
+                if self.rank == 0:
+                    rb = self.recv_host if self.host else (self.recv_pad if ragged else self.recv)
+                else:
+                    rb = None
+                # (gather_column pads the shorter shards itself and needs the caller's row count to be the real total)
+                work, _ = gather_column(src, self.total, dst=0, async_op=True, recv_buffer=rb)
                 work.wait()
+                if self.rank == 0 and ragged and not self.host:
+                    for r, (off, ln) in enumerate(self.parts):
+                        self.recv[off:off + ln].copy_(self.recv_pad[r * self.cap_rows:r * self.cap_rows + ln], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.comm)
             self.done[slot] = ev
+
+    def result(self):
+        """Rank 0, after drain(): the gathered f64 column of the last shipment (total rows); None elsewhere."""
+        if self.rank != 0:
+            return None
+        if self.host and not self.codecs:
+            return torch.cat([self.recv_host[r * self.cap_rows:r * self.cap_rows + ln] for r, (_o, ln) in enumerate(self.parts)]).to(self.dev)
+        return self.recv
 
     def drain(self):
         self.comm.synchronize()
         self.ctx_comm.synchronize()
         self.decode.synchronize()
         self.ctx_decode.synchronize()
+        if self.rank == 0 and int(self.overflow.item()) != 0:
+            raise RuntimeError("ShardGatherer: a rank had more rows outside the codec's table than its exception block "
+                               f"holds ({self.exc_ship}); ship this column as f64 (codec_chars=None) or raise exc_ship")
 
     def exceptions(self):
-        """Rows the codecs could not code in their LAST encode on this rank (must be 0 for the result to be complete)."""
-        return sum(int(c.exc_count.item()) for c in self.codecs.values())
+        """Rows outside the codec's table in the LAST shard this rank coded (they travelled in the exception block)."""
+        n = 0
+        for buf in self.codes.values():
+            n = max(n, int(self._exc_views(buf, self.code_bytes)[0].item()))
+        return n

@@ -22,16 +22,44 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("extra,transport", [([], "9-bit codes, packed"), (["--no-codec"], "f64"), (["--config", "cfg4"], "u16 codes"), (["--measure", "jaccard"], "10-bit codes, packed")])
-def test_two_ranks_ship_and_verify(extra, transport):
+def _run(extra, rows="1000000"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--rows", "1000000", "--backend", "gloo", "--same-device", "--no-cpu-baseline"] + extra
+           "--rows", rows, "--backend", "gloo", "--same-device", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("extra,transport", [([], "9-bit codes, packed"), (["--no-codec"], "f64"), (["--config", "cfg4"], "u16 codes"),
+                                             (["--measure", "jaccard"], "10-bit codes, packed")])
+def test_two_ranks_ship_and_verify(extra, transport):
+    """Strong scaling (the default, = BASELINE's metric): the frame's rows are cut by split_offsets(rows, 2)."""
+    d = _run(extra)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["rows_total"] == 1000000 and d["config"]["rows_rank0"] == 500000
     assert d["config"]["gather_transport"] == transport
     assert d["config"]["gather_verified"] is True
     assert d["config"]["codec_exceptions"] == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-codec"]])
+def test_ragged_shards(extra):
+    """1 000 001 rows over 2 ranks: the last rank's shard is one row longer (strsim.rs:25-35)."""
+    d = _run(extra, rows="1000001")
+    assert d["config"]["rows_rank0"] == 500000 and d["config"]["gather_verified"] is True
+
+
+def test_weak_scaling_option():
+    d = _run(["--scaling", "weak"], rows="300000")
+    assert d["scaling"] == "weak" and d["config"]["rows_total"] == 600000 and d["config"]["gather_verified"] is True
+
+
+def test_codec_exceptions_travel_and_are_patched():
+    """A frame with strings of up to 128 bytes coded with the 32-character tables: every value outside the table (rows with
+    a longer string) has to reach rank 0 through the exception block -- the gathered column must still equal the shards."""
+    d = _run(["--config", "cfg3", "--force-codec"], rows="100000")
+    assert d["config"]["gather_transport"].endswith("codes") or "codes" in d["config"]["gather_transport"]
+    assert d["config"]["codec_exceptions"] > 1000          # the long rows really were exceptions ...
+    assert d["config"]["gather_verified"] is True           # ... and arrived
