@@ -154,12 +154,18 @@ static int ctx_drain(strsim_ctx *c)
         if (!c->slot_pending[s]) continue;
         c->slot_pending[s] = false;
         if (c->slot_timed[s]) {
-            float a = 0, b = 0;
-            HIP_TRY(hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]));
-            HIP_TRY(hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]));
-            c->lane_ms += a; c->wave_ms += b;
-            c->lane_launches++; c->wave_launches++;
+            // every slot is retired whatever fails on the way (a slot left pending would be re-run by a later synchronize
+            // with buffers its caller may have freed); the first error is what the caller gets
             c->slot_timed[s] = false;
+            float a = 0, b = 0;
+            hipError_t e = hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
+            if (e == hipSuccess) {
+                c->lane_ms += a; c->wave_ms += b;
+                c->lane_launches++; c->wave_launches++;
+            } else if (rc == STRSIM_OK) {
+                rc = hip_fail(e, "hipEventElapsedTime");
+            }
         }
         const DevStatus &st = c->status_host[s];
         c->last_wave_rows = st.wave_rows;
@@ -436,13 +442,19 @@ int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const
         }
         uint8_t *h = static_cast<uint8_t *>(c->pin);
         const uint8_t *d = static_cast<const uint8_t *>(c->pin_dev);
-        // offsets keep their base: the value blocks start at the first referenced byte
-        memcpy(h + o_aoff, a_off, (a_rows + 1) * 4);
-        memcpy(h + o_boff, b_off, (b_rows + 1) * 4);
+        // the offsets are rebased to 0 on the way in, so that the kernels get the value blocks' real addresses (with the
+        // caller's base kept and a pointer moved back by it, any kernel access at "offset 0" -- skipped rows of a block,
+        // alignment of a staging copy -- would land a_off[0] bytes in front of the pinned block: a slice of a big column)
+        {
+            uint32_t *ha = reinterpret_cast<uint32_t *>(h + o_aoff), *hb = reinterpret_cast<uint32_t *>(h + o_boff);
+            const uint32_t a0 = a_off[0], b0 = b_off[0];
+            for (uint64_t i = 0; i <= a_rows; ++i) ha[i] = a_off[i] - a0;
+            for (uint64_t i = 0; i <= b_rows; ++i) hb[i] = b_off[i] - b0;
+        }
         if (abytes) memcpy(h + o_aval, a_val + a_off[0], abytes);
         if (bbytes) memcpy(h + o_bval, b_val + b_off[0], bbytes);
-        rc = strsim_pairs_device(c, measure, (const uint32_t *)(d + o_aoff), d + o_aval - a_off[0], a_rows,
-                                 (const uint32_t *)(d + o_boff), d + o_bval - b_off[0], b_rows,
+        rc = strsim_pairs_device(c, measure, (const uint32_t *)(d + o_aoff), d + o_aval, a_rows,
+                                 (const uint32_t *)(d + o_boff), d + o_bval, b_rows,
                                  (double *)(const_cast<uint8_t *>(d) + o_out), n);
         if (rc) return rc;
         rc = strsim_ctx_synchronize(c); // also runs the long-string pass, which writes into the same block
@@ -450,6 +462,8 @@ int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const
         memcpy(out, h + o_out, n * 8);
         return STRSIM_OK;
     }
+    // (the copy path keeps the caller's offset base and uploads the values from byte 0 of the caller's buffer, so every
+    //  offset the kernels can form, 0 included, is inside the device copy)
     const size_t need[5] = {(a_rows + 1) * 4, (size_t)a_off[a_rows] + 1, (b_rows + 1) * 4, (size_t)b_off[b_rows] + 1, n * 8};
     for (int i = 0; i < 5; ++i) {
         rc = ctx_reserve(&c->stage[i], &c->stage_cap[i], need[i]);

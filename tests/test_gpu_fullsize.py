@@ -85,3 +85,92 @@ def test_windows_match_the_oracle(frame, measure):
         got = x[s:s + 50000].cpu().numpy()
         bad = np.nonzero(got.view(np.uint64) != exp.view(np.uint64))[0]
         assert bad.size == 0, (measure, s, int(bad[0]), got[bad[0]], exp[bad[0]])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configs at their full size, on the frames bench.py times (bench_support/workload.py):
+# cfg3 (Jaro-Winkler, 100 M rows, Zipf 4..128 bytes), cfg5 (Levenshtein, 10 M rows, U{1..1024} bytes, held as two row
+# batches because one column is ~5 GB > 32-bit offsets) and cfg4 (all five measures, 200 M rows, the fused call) on one
+# GPU.  Size-independent properties on every row + oracle windows regenerated on the CPU.
+# ---------------------------------------------------------------------------------------------------------------
+SCALE = float(os.environ.get("STRSIM_FULLSIZE_SCALE", "1.0"))  # < 1: smaller frames for a quick local run
+
+
+def _device_frame(name, rows):
+    import torch
+    from bench_support import workload as W
+    measure, _, law, lo, hi, seed = W.CONFIGS[name]
+    mean_len = (lo + hi) / 2.0 if law == W.UNIFORM else 26.0
+    nparts = max(1, int(rows * mean_len * 1.15 / 3.5e9) + (1 if rows * mean_len * 1.15 > 3.5e9 else 0))
+    bounds = [rows * p // nparts for p in range(nparts + 1)]
+    dev = torch.device("cuda", 0)
+    parts = []
+    for p in range(nparts):
+        r0, r1 = bounds[p], bounds[p + 1]
+        oa, va, ob, vb, _, _ = W.device_columns(seed, law, lo, hi, r0, r1 - r0, dev)
+        parts.append((r0, r1, oa, va, ob, vb))
+    return measure, (seed, law, lo, hi), parts
+
+
+def _oracle_windows(measure, cfg, rows, out, win, nwin, seed=11):
+    from bench_support import workload as W
+    s_, law, lo, hi = cfg
+    rng = np.random.default_rng(seed)
+    starts = [0, rows - win] + [int(s) for s in rng.integers(0, rows - win, nwin)]
+    for s in starts:
+        oa, va, ob, vb = W.host_columns(s_, law, lo, hi, s, win)
+        exp = O.batch(measure, oa, va, ob, vb, nthreads=8)
+        got = out[s:s + win].cpu().numpy()
+        bad = np.nonzero(got.view(np.uint64) != exp.view(np.uint64))[0]
+        assert bad.size == 0, (measure, s, int(bad[0]), got[bad[0]], exp[bad[0]])
+
+
+@pytest.mark.parametrize("name,rows,win,nwin", [("cfg3", 100_000_000, 20000, 6), ("cfg5", 10_000_000, 1500, 3)])
+def test_config_frame_full_size(name, rows, win, nwin):
+    import torch as t
+    import strsim_amd as S
+    rows = max(int(rows * SCALE), 4 * win)
+    measure, cfg, parts = _device_frame(name, rows)
+    with S.Context(0, stream=t.cuda.current_stream().cuda_stream) as ctx:
+        def run(swap=False, same=False):
+            out = t.empty(rows, dtype=t.float64, device="cuda")
+            for r0, r1, oa, va, ob, vb in parts:
+                if same:
+                    ctx.pairs_device(measure, oa, va, oa, va, out=out[r0:r1])
+                elif swap:
+                    ctx.pairs_device(measure, ob, vb, oa, va, out=out[r0:r1])
+                else:
+                    ctx.pairs_device(measure, oa, va, ob, vb, out=out[r0:r1])
+            ctx.synchronize()
+            t.cuda.synchronize()
+            return out
+        x = run()
+        assert not bool(t.isnan(x).any()) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+        assert t.equal(x.view(t.int64), run().view(t.int64))                 # deterministic, bit for bit
+        assert bool((run(same=True) == 1.0).all())                            # a == b -> 1.0 (strsim.rs:128, :182)
+        if measure == "levenshtein":
+            assert t.equal(x.view(t.int64), run(swap=True).view(t.int64))     # distance is symmetric
+        _oracle_windows(measure, cfg, rows, x, win, nwin)
+
+
+def test_cfg4_fused_five_outputs_full_size():
+    """cfg4 on one GPU: 200 M rows, one fused pass with five outputs (strsim_pairs_device_all) -- every output column equals,
+    bit for bit, the single-measure call on the same frame, and oracle windows match."""
+    import torch as t
+    import strsim_amd as S
+    rows = max(int(200_000_000 * SCALE), 200_000)
+    _, cfg, parts = _device_frame("cfg4", rows)
+    with S.Context(0, stream=t.cuda.current_stream().cuda_stream) as ctx:
+        outs = [t.empty(rows, dtype=t.float64, device="cuda") for _ in S.MEASURES]
+        for r0, r1, oa, va, ob, vb in parts:
+            ctx.pairs_device_all(oa, va, ob, vb, outs=[o[r0:r1] for o in outs])
+        ctx.synchronize()
+        t.cuda.synchronize()
+        single = t.empty(rows, dtype=t.float64, device="cuda")
+        for k, m in enumerate(S.MEASURES):
+            for r0, r1, oa, va, ob, vb in parts:
+                ctx.pairs_device(m, oa, va, ob, vb, out=single[r0:r1])
+            ctx.synchronize()
+            t.cuda.synchronize()
+            assert t.equal(outs[k].view(t.int64), single.view(t.int64)), m
+            _oracle_windows(m, cfg, rows, outs[k], 20000, 2, seed=40 + k)

@@ -323,6 +323,10 @@ def test_host_calls_in_place_and_copied(S, measure, monkeypatch):
     ao, av = S.pack_strings(A)
     bo, bv = S.pack_strings(B)
     ao7, av7 = (ao + 7).astype(ao.dtype), np.concatenate([np.full(7, 0x7A, np.uint8), av])  # base 7: 7 bytes nobody owns
+    # a base far larger than the offset arrays themselves (a slice deep inside a big Arrow column): 1 MiB of foreign bytes
+    big = 1 << 20
+    aoB, avB = (ao + big).astype(ao.dtype), np.concatenate([np.full(big, 0x7A, np.uint8), av])
+    boB, bvB = (bo + big).astype(bo.dtype), np.concatenate([np.full(big, 0x51, np.uint8), bv])
     lo, lv = S.pack_strings(["phillips"])
     exp_lit = O.batch_strings(measure, A, ["phillips"] * len(A), 8)
     for direct in ("65536", "0"):
@@ -330,6 +334,7 @@ def test_host_calls_in_place_and_copied(S, measure, monkeypatch):
         with S.Context(0) as ctx:
             assert_bit_exact(ctx.pairs_host(measure, ao, av, bo, bv), exp, A, B, "host rows<=%s" % direct)
             assert_bit_exact(ctx.pairs_host(measure, ao7, av7, bo, bv), exp, A, B, "host base 7, rows<=%s" % direct)
+            assert_bit_exact(ctx.pairs_host(measure, aoB, avB, boB, bvB), exp, A, B, "host base 2^20, rows<=%s" % direct)
             assert_bit_exact(ctx.pairs_host(measure, ao, av, lo, lv), exp_lit, A, ["phillips"] * len(A), "host literal")
             for n in (1, 2, 65):
                 o1, v1 = S.pack_strings(A[:n])
