@@ -427,10 +427,19 @@ struct ThreadCtx {
             strsim_ctx_destroy(ctx);
         }
     }
-    strsim_ctx_t *get()
+    // the context of this thread on device `dev` (a thread that is asked for another device than last time starts over)
+    strsim_ctx_t *get(int dev)
     {
+        if (ctx && dev != device) {
+            (void)hipSetDevice(device);
+            for (auto &s : slot) s.release();
+            lit_off.release(); lit_val.release();
+            lit_h_off.release(); lit_h_val.release();
+            strsim_ctx_destroy(ctx);
+            ctx = nullptr;
+        }
         if (!ctx) {
-            if (const char *e = getenv("POLARS_STRSIM_DEVICE")) device = atoi(e);
+            device = dev;
             if (strsim_ctx_create(device, nullptr, &ctx) != STRSIM_OK) fail(strsim_last_error_message());
             lit_off.device = lit_val.device = true;
         }
@@ -439,6 +448,36 @@ struct ThreadCtx {
     }
 };
 thread_local ThreadCtx g_ctx;
+
+// The devices a call may use: POLARS_STRSIM_DEVICES = comma-separated ordinals (an ordinal may repeat: two pipelines on one
+// GPU, which is how the sharding is tested on a one-GPU box), else POLARS_STRSIM_DEVICE = one ordinal, else every visible GPU.
+std::vector<int> plugin_devices()
+{
+    std::vector<int> v;
+    if (const char *e = getenv("POLARS_STRSIM_DEVICES")) {
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            v.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else if (const char *e1 = getenv("POLARS_STRSIM_DEVICE")) {
+        v.push_back(atoi(e1));
+    } else {
+        const int n = strsim_device_count();
+        for (int d = 0; d < n; ++d) v.push_back(d);
+    }
+    if (v.empty()) v.push_back(0); // (no device at all: strsim_ctx_create reports it -- there is no CPU path)
+    return v;
+}
+// rows below which a call is not split any further: a shard should at least fill one pipeline slice
+uint64_t min_rows_per_device()
+{
+    const char *e = getenv("POLARS_STRSIM_MIN_ROWS_PER_DEVICE");
+    return e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : (uint64_t)(2u << 20);
+}
+thread_local ForkJoinPool g_devpool; // one long-lived host thread per extra device (their thread-local contexts persist)
 
 // Small calls: up to this many rows (and direct_bytes() packed bytes per column) the kernels read the pinned staging and write
 // the pinned result buffer through the device's mapping of host memory.  The bytes cross PCIe from inside the kernels
@@ -503,6 +542,126 @@ struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin
     void stop(double &acc) { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// One device's share of a call: rows [lo, hi) of the output through this thread's context on `device` (a two-slot pipeline:
+// pack slice k+1 on the host while the GPU has slice k), results straight into out[lo .. hi).
+void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t lo, uint64_t hi, double *out, unsigned T,
+               bool direct_call, int device, PhaseTimer &tm)
+{
+    strsim_ctx_t *ctx = g_ctx.get(device);
+    hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
+
+    // a literal side is packed and shipped once
+    const uint32_t *lit_off_d = nullptr;
+    const uint8_t *lit_val_d = nullptr;
+    for (int s = 0; s < 2; ++s) {
+        if (!lit[s]) continue;
+        Buf &ho = g_ctx.lit_h_off, &hv = g_ctx.lit_h_val; // persistent pinned staging: the call is synchronous,
+        const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
+        if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
+        if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
+            lit_off_d = static_cast<const uint32_t *>(mapped(ho.p));
+            lit_val_d = static_cast<const uint8_t *>(mapped(hv.p));
+            continue;
+        }
+        g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
+        g_ctx.lit_val.reserve(bytes + 64);
+        HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (bytes) HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream));
+        lit_off_d = static_cast<const uint32_t *>(g_ctx.lit_off.p);
+        lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
+    }
+
+    // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
+    auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
+        uint64_t rows = std::min<uint64_t>(want, hi - r0);
+        for (;;) {
+            bool fits = true;
+            for (int s = 0; s < 2 && fits; ++s) {
+                if (lit[s]) continue;
+                sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
+                fits = sl.bytes[s] <= SLICE_BYTES;
+            }
+            if (fits) break;
+            if (rows == 1) fail("a single string exceeds the 4 GiB limit");
+            rows = (rows + 1) / 2; // very long strings: halve the slice until its packed values fit 32-bit offsets
+        }
+        sl.r0 = r0; sl.rows = rows;
+        return rows;
+    };
+    auto launch = [&](Slot &sl) {
+        const uint32_t *doff[2];
+        const uint8_t *dval[2];
+        uint64_t drows[2];
+        sl.direct = direct_call;
+        for (int s = 0; s < 2; ++s)
+            if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
+        for (int s = 0; s < 2; ++s) {
+            if (lit[s]) { doff[s] = lit_off_d; dval[s] = lit_val_d; drows[s] = 1; continue; }
+            drows[s] = sl.rows;
+            if (sl.direct) {
+                doff[s] = static_cast<const uint32_t *>(mapped(sl.h_off[s].p));
+                dval[s] = static_cast<const uint8_t *>(mapped(sl.h_val[s].p));
+                continue;
+            }
+            sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
+            sl.d_val[s].reserve(sl.bytes[s] + 64);
+            HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
+            doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
+            dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
+        }
+        sl.h_out.reserve(sl.rows * sizeof(double));
+        if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
+        double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
+        if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
+            fail(strsim_last_error_message());
+        // results come back right behind the kernels (no separate round trip later)
+        if (!sl.direct)
+            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+    };
+    auto wait = [&](Slot &sl) {
+        tm.start();
+        if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+        tm.stop(tm.t_wait);
+        if (strsim_ctx_last_long_rows(ctx) != 0 && !sl.direct) { // rows finished by that pass: fetch the column again
+            tm.start();
+            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_OR_FAIL(hipStreamSynchronize(stream));
+            tm.stop(tm.t_d2h);
+        }
+    };
+    auto copy_out = [&](Slot &sl) {
+        tm.start();
+        const double *src = static_cast<const double *>(sl.h_out.p);
+        const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
+        fork_join(Tc, [&](unsigned t) {
+            const uint64_t i0 = sl.rows * t / Tc, i1 = sl.rows * (t + 1) / Tc;
+            memcpy(out + sl.r0 + i0, src + i0, (i1 - i0) * sizeof(double));
+        });
+        tm.stop(tm.t_copy);
+    };
+
+    // two slots: while the GPU works on slot `cur` (H2D, kernels, D2H) the host packs the next slice into the other
+    // slot, and it copies a finished slice out only after the next one has been launched
+    uint64_t r0 = lo;
+    int cur = 0;
+    // (cutting a 1 M-row call into four slices so that it pipelines too was tried: the four small packs cost
+    // 1.3 ms instead of 0.6 ms and the call got slower)
+    const uint64_t slice_rows = SLICE_ROWS;
+    tm.start(); r0 += pack(g_ctx.slot[cur], r0, slice_rows); tm.stop(tm.t_pack);
+    tm.start(); launch(g_ctx.slot[cur]); tm.stop(tm.t_launch);
+    while (r0 < hi) {
+        const int nxt = cur ^ 1;
+        tm.start(); r0 += pack(g_ctx.slot[nxt], r0, slice_rows); tm.stop(tm.t_pack); // overlaps the GPU work of slot `cur`
+        wait(g_ctx.slot[cur]);
+        tm.start(); launch(g_ctx.slot[nxt]); tm.stop(tm.t_launch);
+        copy_out(g_ctx.slot[cur]); // overlaps the GPU work of slot `nxt`
+        cur = nxt;
+    }
+    wait(g_ctx.slot[cur]);
+    copy_out(g_ctx.slot[cur]);
+}
+
 void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)
 {
     PhaseTimer tm;
@@ -530,121 +689,28 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     const bool all_null = (lit[0] && !row_valid(a, 0)) || (lit[1] && !row_valid(b, 0));
 
     if (n != 0 && !all_null) {
-        strsim_ctx_t *ctx = g_ctx.get();
-        hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
-        const unsigned T = pack_threads(engine_parallel, n);
+        // Rows shard over the GPUs the way the reference shards them over its threads (strsim.rs:72-100): contiguous ranges by
+        // split_offsets(n, devices) (strsim.rs:21-39), one pipeline per device on its own host thread, each shipping its
+        // slices over its own PCIe link and copying its results into its part of the output -- no collective in one process.
+        const std::vector<int> devs = plugin_devices();
         const bool direct_call = n <= direct_rows();
-
-        // a literal side is packed and shipped once
-        const uint32_t *lit_off_d = nullptr;
-        const uint8_t *lit_val_d = nullptr;
-        for (int s = 0; s < 2; ++s) {
-            if (!lit[s]) continue;
-            Buf &ho = g_ctx.lit_h_off, &hv = g_ctx.lit_h_val; // persistent pinned staging: the call is synchronous,
-            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
-            if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
-            if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
-                lit_off_d = static_cast<const uint32_t *>(mapped(ho.p));
-                lit_val_d = static_cast<const uint8_t *>(mapped(hv.p));
-                continue;
-            }
-            g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
-            g_ctx.lit_val.reserve(bytes + 64);
-            HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            if (bytes) HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream));
-            lit_off_d = static_cast<const uint32_t *>(g_ctx.lit_off.p);
-            lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
-        }
-
-        // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
-        auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
-            uint64_t rows = std::min<uint64_t>(want, n - r0);
-            for (;;) {
-                bool fits = true;
-                for (int s = 0; s < 2 && fits; ++s) {
-                    if (lit[s]) continue;
-                    sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
-                    fits = sl.bytes[s] <= SLICE_BYTES;
-                }
-                if (fits) break;
-                if (rows == 1) fail("a single string exceeds the 4 GiB limit");
-                rows = (rows + 1) / 2; // very long strings: halve the slice until its packed values fit 32-bit offsets
-            }
-            sl.r0 = r0; sl.rows = rows;
-            return rows;
-        };
-        auto launch = [&](Slot &sl) {
-            const uint32_t *doff[2];
-            const uint8_t *dval[2];
-            uint64_t drows[2];
-            sl.direct = direct_call;
-            for (int s = 0; s < 2; ++s)
-                if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
-            for (int s = 0; s < 2; ++s) {
-                if (lit[s]) { doff[s] = lit_off_d; dval[s] = lit_val_d; drows[s] = 1; continue; }
-                drows[s] = sl.rows;
-                if (sl.direct) {
-                    doff[s] = static_cast<const uint32_t *>(mapped(sl.h_off[s].p));
-                    dval[s] = static_cast<const uint8_t *>(mapped(sl.h_val[s].p));
-                    continue;
-                }
-                sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
-                sl.d_val[s].reserve(sl.bytes[s] + 64);
-                HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
-                doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
-                dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
-            }
-            sl.h_out.reserve(sl.rows * sizeof(double));
-            if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
-            double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
-            if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
-                fail(strsim_last_error_message());
-            // results come back right behind the kernels (no separate round trip later)
-            if (!sl.direct)
-                HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
-        };
-        auto wait = [&](Slot &sl) {
-            tm.start();
-            if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
-            tm.stop(tm.t_wait);
-            if (strsim_ctx_last_long_rows(ctx) != 0 && !sl.direct) { // rows finished by that pass: fetch the column again
-                tm.start();
-                HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
-                HIP_OR_FAIL(hipStreamSynchronize(stream));
-                tm.stop(tm.t_d2h);
-            }
-        };
-        auto copy_out = [&](Slot &sl) {
-            tm.start();
-            const double *src = static_cast<const double *>(sl.h_out.p);
-            const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
-            fork_join(Tc, [&](unsigned t) {
-                const uint64_t i0 = sl.rows * t / Tc, i1 = sl.rows * (t + 1) / Tc;
-                memcpy(out + sl.r0 + i0, src + i0, (i1 - i0) * sizeof(double));
+        const uint64_t D = std::max<uint64_t>(1, std::min<uint64_t>(devs.size(), n / min_rows_per_device()));
+        const unsigned T = std::max(1u, pack_threads(engine_parallel, n) / (unsigned)D);
+        if (D == 1) {
+            run_shard(measure, col, lit, 0, n, out, T, direct_call, devs[0], tm);
+        } else {
+            std::vector<uint64_t> parts(2 * D);
+            strsim_split_offsets(n, D, parts.data());
+            std::vector<PhaseTimer> tms(D);
+            g_devpool.run((unsigned)D, [&](unsigned d) {
+                run_shard(measure, col, lit, parts[2 * d], parts[2 * d] + parts[2 * d + 1], out, T, false, devs[d], tms[d]);
             });
-            tm.stop(tm.t_copy);
-        };
-
-        // two slots: while the GPU works on slot `cur` (H2D, kernels, D2H) the host packs the next slice into the other
-        // slot, and it copies a finished slice out only after the next one has been launched
-        uint64_t r0 = 0;
-        int cur = 0;
-        // (cutting a 1 M-row call into four slices so that it pipelines too was tried: the four small packs cost
-        // 1.3 ms instead of 0.6 ms and the call got slower)
-        const uint64_t slice_rows = SLICE_ROWS;
-        tm.start(); r0 += pack(g_ctx.slot[cur], r0, slice_rows); tm.stop(tm.t_pack);
-        tm.start(); launch(g_ctx.slot[cur]); tm.stop(tm.t_launch);
-        while (r0 < n) {
-            const int nxt = cur ^ 1;
-            tm.start(); r0 += pack(g_ctx.slot[nxt], r0, slice_rows); tm.stop(tm.t_pack); // overlaps the GPU work of slot `cur`
-            wait(g_ctx.slot[cur]);
-            tm.start(); launch(g_ctx.slot[nxt]); tm.stop(tm.t_launch);
-            copy_out(g_ctx.slot[cur]); // overlaps the GPU work of slot `nxt`
-            cur = nxt;
+            for (const PhaseTimer &t : tms) { // (phase times of the shards ran concurrently: the longest of each is what the call saw)
+                tm.t_pack = std::max(tm.t_pack, t.t_pack); tm.t_wait = std::max(tm.t_wait, t.t_wait);
+                tm.t_d2h = std::max(tm.t_d2h, t.t_d2h); tm.t_copy = std::max(tm.t_copy, t.t_copy);
+                tm.t_launch = std::max(tm.t_launch, t.t_launch);
+            }
         }
-        wait(g_ctx.slot[cur]);
-        copy_out(g_ctx.slot[cur]);
     }
 
     // output validity = AND of the input validities (broadcast for a literal)

@@ -172,3 +172,25 @@ def test_concurrent_calls_from_several_threads(H):
     for t_ in th:
         t_.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("devices,min_rows", [("0,0", "1000"), ("0,0,0", "50000")])
+def test_rows_shard_over_several_device_pipelines(H, monkeypatch, devices, min_rows):
+    """One plugin call, several device pipelines (the reference fans rows out over its threads inside the call,
+    strsim.rs:72-100): rows are cut by split_offsets(n, devices) (strsim.rs:21-39), every shard runs on its own host thread
+    with its own context and pinned slots.  A one-GPU box runs the shards as several contexts on device 0; nulls, a literal
+    and strings that need the slow kernels included; then the same thread goes back to one device."""
+    monkeypatch.setenv("POLARS_STRSIM_DEVICES", devices)
+    monkeypatch.setenv("POLARS_STRSIM_MIN_ROWS_PER_DEVICE", min_rows)
+    A, B = gen.pairs(77, 200_003, gen.ASCII_LOWER, 0, 40)
+    A2, B2 = gen.pairs(78, 3000, gen.MIXED, 0, 150)
+    A, B = A + A2, B + B2
+    A[5] = None
+    B[100_000] = None
+    A[-1] = "z" * 1300
+    for m in ("levenshtein", "jaro_winkler", "jaccard"):
+        check(H.call_plugin(m, A, B), expect(m, A, B))
+    check(H.call_plugin("levenshtein", A, "phillips"), expect("levenshtein", A, ["phillips"]))
+    check(H.call_plugin("jaro", "philips", B), expect("jaro", ["philips"], B))
+    monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
+    check(H.call_plugin("sorensen_dice", A[:70000], B[:70000]), expect("sorensen_dice", A[:70000], B[:70000]))
