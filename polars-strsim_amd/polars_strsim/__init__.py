@@ -5,6 +5,10 @@ Same five expression functions, signatures and `is_elementwise=True` registratio
 shared library, finds libpolars_strsim_amd.so (built here by ../Makefile) and calls its
 `_polars_plugin_<name>` symbols (include/polars_plugin_abi.h), which run on the GPU.
 """
+import ctypes as _C
+import importlib.util as _ilu
+import os as _os
+import sys as _sys
 from pathlib import Path
 
 import polars as pl
@@ -14,6 +18,30 @@ from polars.plugins import register_plugin_function
 from polars_strsim.utils import parse_into_expr
 
 _PLUGIN_DIR = Path(__file__).parent
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process (the same rule as strsim_amd/_lib.py, for the route where POLARS loads the library).
+
+    Polars dlopen()s libpolars_strsim_amd.so on the first plugin call; it then binds /opt/rocm's libamdhip64.  A torch wheel
+    brings its own copy, and an `import torch` AFTER that maps the second runtime next to the first -- whichever initialises
+    second finds "No HIP GPUs".  When torch is installed but not imported yet, its copy is mapped first (by SONAME both
+    then resolve to it); when torch is already imported nothing needs doing; without torch the system runtime is used.
+    Set STRSIM_KEEP_SYSTEM_HIP=1 to switch this off."""
+    if "torch" in _sys.modules or _os.environ.get("STRSIM_KEEP_SYSTEM_HIP"):
+        return
+    try:
+        spec = _ilu.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = _os.path.join(_os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if _os.path.exists(bundled):
+        _C.CDLL(bundled, mode=_C.RTLD_GLOBAL)
+
+
+_share_hip_runtime_with_torch()
 
 
 def _similarity(function_name: str, expr: IntoExpr, other: IntoExpr) -> pl.Expr:
