@@ -351,6 +351,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
+    la.no_literal_path = getenv("STRSIM_NO_LITERAL_PATH") != nullptr; // (tuning / A-B knob)
     la.wide_grid = c->num_cu * 3; // resident (LDS)
     {
         int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)

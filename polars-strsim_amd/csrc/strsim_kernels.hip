@@ -271,6 +271,7 @@ k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
 }
 
 #include "strsim_lane_stage.h"
+#include "strsim_lane_lit.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_wide: one pair per lane for the rows k_lane_pairs left behind whose strings are 33..128 ASCII
@@ -1803,7 +1804,16 @@ static void launch_pair(const LaunchArgs &a)
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
-    if (a.stage_grid > 0) {
+    if (a.stage_grid > 0 && M == LEVENSHTEIN && (a.rowsA == 1 || a.rowsB == 1) && !a.no_literal_path) {
+        // a column against a literal (strsim_lane_lit.h): the literal is the wave-uniform text, the column is staged
+        const bool litA = a.rowsA == 1 && a.rowsB != 1;
+        const uint64_t nlb = (a.n + (LIT_ROWS - 1)) / LIT_ROWS;
+        const uint64_t want = (uint64_t)a.stage_grid * 3u; // ~15 workgroups per CU in the launch, 5 resident
+        const uint64_t gl = nlb < want ? nlb : want;
+        hipLaunchKernelGGL(k_lane_lit_lev, dim3((unsigned)gl), dim3(LIT_BLOCK), 0, a.stream, litA ? a.offB : a.offA,
+                           litA ? a.valB : a.valA, litA ? a.offA : a.offB, litA ? a.valA : a.valB, a.out, a.n, a.slowmask,
+                           a.status, a.qtab);
+    } else if (a.stage_grid > 0) {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;

@@ -187,11 +187,26 @@ def test_row_counts(S, ctx, measure, n):
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_literal_broadcast(S, ctx, measure):
     A, B = gen.pairs(3, 5000, gen.ASCII_LOWER, 0, 32)
-    for lit in ("phillips", "", "é", "x" * 40):
+    # literals of every class: short, empty, one byte, exactly 32 bytes, odd / even lengths, mixed case (seven bit-planes),
+    # non-ASCII and longer than the lane path takes (both leave the rows to the later kernels)
+    for lit in ("phillips", "", "q", "abcdefghijklmnopqrstuvwxyzabcdef", "philips", "McDonald's", "é", "x" * 40):
         got = gpu(S, ctx, measure, A, [lit])
         assert_bit_exact(got, O.batch_strings(measure, A, [lit], 4), A, [lit], measure + " col,lit")
         got = gpu(S, ctx, measure, [lit], B)
         assert_bit_exact(got, O.batch_strings(measure, [lit], B, 4), [lit], B, measure + " lit,col")
+
+
+def test_literal_against_every_row_class(S, ctx):
+    """The column-x-literal kernel (k_lane_lit_lev) on a frame that mixes everything: short ASCII, empty strings, non-ASCII,
+    33..900-byte rows (blocks get cut to the staging area), more rows than one range; literal on either side."""
+    A, _ = gen.pairs(61, 150_000, gen.ASCII_LOWER, 0, 32)
+    A2, _ = gen.pairs(62, 3000, gen.MIXED, 0, 120)
+    A3, _ = gen.pairs(63, 300, gen.ASCII_LOWER, 200, 900)
+    A = A[:70_000] + A2 + A[70_000:] + A3 + ["", "phillips", "a" * 32]
+    for lit in ("phillips", "sm", "abcdefghijklmnopqrstuvwxyzabcde"):
+        exp = O.batch_strings("levenshtein", A, [lit], 8)
+        assert_bit_exact(gpu(S, ctx, "levenshtein", A, [lit]), exp, A, [lit], "col,lit " + lit)
+        assert_bit_exact(gpu(S, ctx, "levenshtein", [lit], A), exp, [lit], A, "lit,col " + lit)
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
