@@ -8,5 +8,5 @@ namespace strsim {
 #define PROBE_M 0
 #endif
 template __global__ void k_lane_stage<PROBE_M>(const uint32_t *, const uint8_t *, uint64_t, const uint32_t *, const uint8_t *, uint64_t,
-                                        double *, uint64_t, unsigned long long *, DevStatus *, const double *, uint32_t *);
+                                        double *, uint64_t, unsigned long long *, DevStatus *, const double *, uint32_t *, DevStatus *);
 }

@@ -99,6 +99,15 @@ STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
                         double *out, uint64_t out_rows);
 
+/* strsim_pairs_device for a SMALL call that the caller synchronises right away (strsim_pairs_host's in-place path, the
+ * plugin's direct path; reference: one `compute` per row on the calling thread, strsim.rs:53-70).  May block until the
+ * one-pair-per-lane kernel has finished: when that kernel leaves no row behind -- short ASCII strings, the common case --
+ * the call is complete after one kernel launch and nothing is pending; otherwise the remaining kernels are enqueued and the
+ * call completes in strsim_ctx_synchronize() like any other.  Same arguments and errors as strsim_pairs_device. */
+STRSIM_API int strsim_pairs_device_small(strsim_ctx_t *ctx, int measure, const uint32_t *a_offsets, const uint8_t *a_values,
+                                         uint64_t a_rows, const uint32_t *b_offsets, const uint8_t *b_values, uint64_t b_rows,
+                                         double *out, uint64_t out_rows);
+
 /*
  * All five measures of the same two column shards in one call (BASELINE config 4): the rows that fit the
  * lane-per-pair path are read once and produce five outputs from one set of bit-planes; `outs` is indexed by

@@ -613,7 +613,8 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         sl.h_out.reserve(sl.rows * sizeof(double));
         if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
         double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
-        if (strsim_pairs_device(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
+        // (a slice computed in place is a small call: one launch when the lane kernel leaves nothing behind)
+        if ((sl.direct ? strsim_pairs_device_small : strsim_pairs_device)(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
             fail(strsim_last_error_message());
         // results come back right behind the kernels (no separate round trip later)
         if (!sl.direct)

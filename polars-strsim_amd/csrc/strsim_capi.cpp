@@ -64,7 +64,7 @@ struct strsim_ctx {
     // back to back without a host sync; the ring is drained by strsim_ctx_synchronize()
     static constexpr int RING = 32;
     DevStatus *status = nullptr;      // device, RING entries
-    uint32_t *sched = nullptr;        // device, RING x 2 words: work-distribution counters of k_lane_stage (zero between launches)
+    uint32_t *sched = nullptr;        // device, RING x 4 words: work-distribution counters of k_lane_stage (zero between launches)
     DevStatus *status_host = nullptr; // pinned, RING entries
     DevStatus *status_host_dev = nullptr; // the same memory as the device addresses it
     void *pin = nullptr;   // pinned staging of strsim_pairs_host's small calls (kernels work on it in place)
@@ -241,10 +241,10 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         c->own_stream = true;
     }
     e = hipMalloc((void **)&c->status, sizeof(DevStatus) * strsim_ctx::RING);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->sched, sizeof(uint32_t) * 2 * strsim_ctx::RING);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->sched, sizeof(uint32_t) * 4 * strsim_ctx::RING);
     // (cleared on the context's own stream: a memset on the null stream would bring the legacy default stream into a process
     //  that may initialise torch's runtime later, tests/test_hip_runtime_sharing.py)
-    if (e == hipSuccess) e = hipMemsetAsync(c->sched, 0, sizeof(uint32_t) * 2 * strsim_ctx::RING, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->sched, 0, sizeof(uint32_t) * 4 * strsim_ctx::RING, c->stream);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->status_host, sizeof(DevStatus) * strsim_ctx::RING, hipHostMallocDefault);
     if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "status allocation"); }
@@ -300,7 +300,7 @@ void strsim_split_offsets(uint64_t len, uint64_t n, uint64_t *out)
 
 static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
                              const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *const *outs,
-                             uint64_t out_rows)
+                             uint64_t out_rows, bool eager = false)
 {
     const bool all = measure == STRSIM_NUM_MEASURES;
     if (!c) { set_error("strsim_pairs_device: ctx is NULL"); return STRSIM_ERR_ARG; }
@@ -346,7 +346,8 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
     la.out = outs[0]; la.n = n;
     la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
-    la.sched = c->sched + 2 * slot;
+    la.sched = c->sched + 4 * slot;
+    la.publish_host = nullptr;
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
     la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
@@ -377,6 +378,36 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
             if (!c->ev[slot][i]) HIP_TRY(hipEventCreateWithFlags(&c->ev[slot][i], hipEventDisableSystemFence));
         la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
     }
+    if (eager && !all && la.stage_grid > 0 && !c->timing) {
+        // Small call the caller is going to wait for anyway: launch the one-pair-per-lane kernel alone, let its last
+        // workgroup report how many rows it left (host-mapped status word) and wait for it.  Usually that is none --
+        // short ASCII strings -- and the call is done after ONE kernel launch instead of five (the three slow-row kernels
+        // and the status copy cost ~4 us each even when they find nothing to do).
+        la.no_literal_path = true; // (k_lane_stage reports; it broadcasts a literal itself)
+        la.publish_host = c->status_host_dev + slot;
+        c->status_host[slot].lane_left = 0xFFFFFFFFu;
+        hipError_t e0 = launch_lane_only(measure, la);
+        if (e0 != hipSuccess) return hip_fail(e0, "kernel launch");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t left = *reinterpret_cast<volatile uint32_t *>(&c->status_host[slot].lane_left);
+        if (getenv("STRSIM_TRACE")) fprintf(stderr, "[strsim] eager call: %llu rows, %u left behind the lane kernel\n", (unsigned long long)n, left);
+        if (left == 0u) {
+            c->last_wave_rows = 0;
+            c->last_long_rows = 0;
+            return STRSIM_OK; // nothing pending: strsim_ctx_synchronize() has nothing to retire for this call
+        }
+        la.publish_host = nullptr;
+        e0 = launch_slow_only(measure, la);
+        if (e0 != hipSuccess) return hip_fail(e0, "kernel launch");
+        c->slot_timed[slot] = false;
+        c->slot_args[slot] = la;
+        c->slot_measure[slot] = measure;
+        for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = nullptr;
+        HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->stream));
+        c->slot_pending[slot] = true;
+        c->head = (slot + 1) % strsim_ctx::RING;
+        return STRSIM_OK;
+    }
     hipError_t e = all ? launch_pairs_all(la, outs, c->slowmask + nchunks) : launch_pairs(measure, la);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     c->slot_timed[slot] = c->timing;
@@ -395,6 +426,14 @@ int strsim_pairs_device(strsim_ctx_t *c, int measure, const uint32_t *a_off, con
     if (measure == STRSIM_NUM_MEASURES) { set_error("strsim_pairs_device: unknown measure %d", measure); return STRSIM_ERR_ARG; }
     double *outs[1] = {out};
     return pairs_device_impl(c, measure, a_off, a_val, a_rows, b_off, b_val, b_rows, out ? outs : nullptr, out_rows);
+}
+
+int strsim_pairs_device_small(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
+                              const uint32_t *b_off, const uint8_t *b_val, uint64_t b_rows, double *out, uint64_t out_rows)
+{
+    if (measure == STRSIM_NUM_MEASURES) { set_error("strsim_pairs_device_small: unknown measure %d", measure); return STRSIM_ERR_ARG; }
+    double *outs[1] = {out};
+    return pairs_device_impl(c, measure, a_off, a_val, a_rows, b_off, b_val, b_rows, out ? outs : nullptr, out_rows, true);
 }
 
 int strsim_pairs_device_all(strsim_ctx_t *c, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
@@ -454,9 +493,9 @@ int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const
         }
         if (abytes) memcpy(h + o_aval, a_val + a_off[0], abytes);
         if (bbytes) memcpy(h + o_bval, b_val + b_off[0], bbytes);
-        rc = strsim_pairs_device(c, measure, (const uint32_t *)(d + o_aoff), d + o_aval, a_rows,
-                                 (const uint32_t *)(d + o_boff), d + o_bval, b_rows,
-                                 (double *)(const_cast<uint8_t *>(d) + o_out), n);
+        rc = strsim_pairs_device_small(c, measure, (const uint32_t *)(d + o_aoff), d + o_aval, a_rows,
+                                       (const uint32_t *)(d + o_boff), d + o_bval, b_rows,
+                                       (double *)(const_cast<uint8_t *>(d) + o_out), n);
         if (rc) return rc;
         rc = strsim_ctx_synchronize(c); // also runs the long-string pass, which writes into the same block
         if (rc) return rc;

@@ -32,7 +32,7 @@ struct DevStatus {
     unsigned int wave_rows; // rows finished by k_wave_pairs
     unsigned int huge_rows; // rows longer than WAVE_CAP (left for the long-string pass)
     unsigned int max_len;   // longest such string, bytes
-    unsigned int pad0;
+    unsigned int lane_left; // rows the one-pair-per-lane kernel left to the kernels behind it (written for eager calls only)
     // per measure (the fused five-measure call runs the slow-row kernels once per measure):
     unsigned int list_count[5]; // k_lane_utf8: chunks of 64 rows that still hold unfinished rows ...
     unsigned int list_rows[5];  // ... and how many rows that is
@@ -49,7 +49,8 @@ struct LaunchArgs {
     uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
     const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of k_lane_pairs (device)
     DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
-    uint32_t *sched;              // k_lane_stage: two zeroed words (range counter, finished workgroups); left zeroed by the kernel
+    uint32_t *sched;              // k_lane_stage: four zeroed words (range counter, finished workgroups, rows left, -); left zeroed by the kernel
+    DevStatus *publish_host;      // eager small calls: the last workgroup of k_lane_stage writes lane_left there (host-mapped), else nullptr
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     bool no_literal_path;         // A/B runs: a literal call takes k_lane_stage like any other
@@ -61,6 +62,9 @@ struct LaunchArgs {
 };
 
 hipError_t launch_pairs(int measure, const LaunchArgs &a);
+// the two halves of launch_pairs for a call that looks at lane_left in between (small calls: usually nothing is left)
+hipError_t launch_lane_only(int measure, const LaunchArgs &a);
+hipError_t launch_slow_only(int measure, const LaunchArgs &a);
 
 // All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
 hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);

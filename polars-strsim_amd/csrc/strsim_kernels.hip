@@ -1792,7 +1792,7 @@ static void wide_geometry(const LaunchArgs &a, uint32_t &sps, unsigned &grid)
 }
 
 template <int M>
-static void launch_pair(const LaunchArgs &a)
+static void launch_lane_t(const LaunchArgs &a)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
     const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
@@ -1818,12 +1818,22 @@ static void launch_pair(const LaunchArgs &a)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;
         hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab, a.sched);
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
     } else {
         hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
+}
+
+template <int M>
+static void launch_slow_t(const LaunchArgs &a)
+{
+    const uint64_t nchunks = (a.n + 63u) >> 6;
+    // waves per CU: Levenshtein by its 8 KB table; Jaro by its 12.4 KB of LDS (12); Jaccard / Dice 16 (a.wave_grid)
+    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
+                        : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 4u : (uint64_t)a.wave_grid;
+    const uint64_t g2 = nchunks < wg ? nchunks : wg;
     {
         uint32_t sps;
         unsigned g3;
@@ -1836,6 +1846,14 @@ static void launch_pair(const LaunchArgs &a)
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
+}
+
+
+template <int M>
+static void launch_pair(const LaunchArgs &a)
+{
+    launch_lane_t<M>(a);
+    launch_slow_t<M>(a);
 }
 
 template <int M>
@@ -1905,6 +1923,34 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
         }
     }
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_lane_only(int measure, const LaunchArgs &a)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (measure) {
+    case LEVENSHTEIN: launch_lane_t<LEVENSHTEIN>(a); break;
+    case JARO: launch_lane_t<JARO>(a); break;
+    case JARO_WINKLER: launch_lane_t<JARO_WINKLER>(a); break;
+    case JACCARD: launch_lane_t<JACCARD>(a); break;
+    case SORENSEN_DICE: launch_lane_t<SORENSEN_DICE>(a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_slow_only(int measure, const LaunchArgs &a)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (measure) {
+    case LEVENSHTEIN: launch_slow_t<LEVENSHTEIN>(a); break;
+    case JARO: launch_slow_t<JARO>(a); break;
+    case JARO_WINKLER: launch_slow_t<JARO_WINKLER>(a); break;
+    case JACCARD: launch_slow_t<JACCARD>(a); break;
+    case SORENSEN_DICE: launch_slow_t<SORENSEN_DICE>(a); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

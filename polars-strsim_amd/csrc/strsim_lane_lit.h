@@ -24,8 +24,8 @@ constexpr int LIT_WAVES = LIT_BLOCK / 64;
 constexpr int LIT_ROWS = 512;                 // rows per block (at most)
 constexpr int LIT_RPT = LIT_ROWS / LIT_BLOCK;
 constexpr int LIT_CAP = 10240;                // staged bytes per block
-constexpr int LIT_COL = LIT_CAP + 64;
-constexpr int LIT_DMA_ITERS = (LIT_CAP + 16 * LIT_BLOCK - 1) / (16 * LIT_BLOCK);
+constexpr int LIT_COL = LIT_CAP + 96;                // + 32 bytes behind the block, a chunk's rounding, 32 zeros
+constexpr int LIT_DMA_ITERS = (LIT_CAP + 48 + 16 * LIT_BLOCK - 1) / (16 * LIT_BLOCK);
 
 // Levenshtein column loop with a wave-uniform text of exactly lt characters (lt >= 1): lt columns for every lane, the
 // distance is lt + (vertical +1 deltas) - (vertical -1 deltas) over the lp pattern rows of the last column.
@@ -127,15 +127,19 @@ k_lane_lit_lev(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ va
         if (k == 0u) k = 1u;
         return uniform(k * 64u < avail ? k * 64u : avail);
     };
-    auto dma_bytes = [&](uint32_t base, uint32_t mis, uint32_t end, uint32_t buf) -> uint32_t { // -> bytes staged
+    auto dma_bytes = [&](uint32_t base, uint32_t mis, uint32_t end, uint32_t buf) -> uint32_t { // -> bytes the strings may use
         const uint32_t span = end - base + mis;
-        const uint32_t chunks = ((span < (uint32_t)LIT_CAP ? span : (uint32_t)LIT_CAP) + 15u) >> 4;
+        const uint32_t staged = ((span < (uint32_t)LIT_CAP ? span : (uint32_t)LIT_CAP) + 15u) & ~15u;
+        // + the 32 bytes behind the block when the column has them, then 32 zeros (see k_lane_stage: no stale LDS in a window)
+        const uint32_t left = totalC - base + mis;
+        const uint32_t chunks = ((staged + 32u < left ? staged + 32u : left) + 15u) >> 4;
         const uint8_t *const g = valC + base - mis;
 #pragma unroll
         for (int it = 0; it < LIT_DMA_ITERS; ++it)
             if (tid + (uint32_t)it * LIT_BLOCK < chunks)
                 lds_dma_b128(g + 16 * it * LIT_BLOCK, tid16, ldsBytes + buf * (uint32_t)LIT_COL + 16u * ((uint32_t)it * LIT_BLOCK + wvu * 64u));
-        return chunks << 4;
+        if (tid < 2u) *reinterpret_cast<uint4 *>(&s_bytes[buf][(chunks << 4) + tid * 16u]) = make_uint4(0u, 0u, 0u, 0u);
+        return staged;
     };
     auto store_block = [&](uint64_t r0, uint32_t rows, uint32_t buf) {
         double *__restrict__ const outb = out + r0;

@@ -60,8 +60,8 @@ constexpr int STAGE_RPT = STAGE_ROWS / STAGE_BLOCK;   // rows per thread in the 
 constexpr int STAGE_NR = STAGE_ROWS / 64;             // rounds per block
 constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and block
 constexpr int STAGE_CAP = STRSIM_STAGE_CAP;           // staged bytes per column
-constexpr int STAGE_COL = STAGE_CAP + 64;             // LDS bytes per column (a window may start at the last staged byte)
-constexpr int STAGE_DMA_ITERS = (STAGE_CAP + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
+constexpr int STAGE_COL = STAGE_CAP + 96;             // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
+constexpr int STAGE_DMA_ITERS = (STAGE_CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
 constexpr int STAGE_BSH = STRSIM_STAGE_BUCKET_SHIFT;  // buckets of 2^BSH column counts
 constexpr int STAGE_NBK = (32 >> STAGE_BSH) + 1;      // + one for the rows this kernel leaves to the later ones
 static_assert(STAGE_RPT >= 1 && STAGE_RPT <= 4 && STAGE_RPW >= 1, "STAGE_ROWS is 256, 512 or 1024");
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STR
 k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, double *__restrict__ out,
              uint64_t n, unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
-             const double *__restrict__ qtab, uint32_t *__restrict__ sched)
+             const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
@@ -189,6 +189,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 4]; // offsets of the rows from the next block's start on
     __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_left;                // rows of this workgroup's blocks that stay in the mask
     __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
     __shared__ uint2 s_desc[B];
     __shared__ uint16_t s_code[LEV ? B : 1];   // Levenshtein: table index per row, 0xFFFF = not computed here
@@ -198,6 +199,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
     if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
     if (tid < 32u) s_cnt[tid] = 0u;
+    if (tid == 0u) s_left = 0u;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
@@ -311,7 +313,10 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
                 if (valid && !undone) outb[i] = v;
-                if (lane == 0u && valid) maskb[i >> 6] = left;
+                if (lane == 0u && valid) {
+                    maskb[i >> 6] = left;
+                    if (publish && left) atomicAdd(&s_left, (uint32_t)__builtin_popcountll(left));
+                }
             }
         }
     };
@@ -351,8 +356,17 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         // ---- A: bytes DMA(j).  Column side X: the 16-byte chunks from the aligned address below the block's first byte
         //         up to the block's last byte, at most STAGE_CAP bytes -> s_bytes[X]
         const uint32_t spanA = endA - baseA + misA, spanB = endB - baseB + misB;
-        const uint32_t chunksA = bcastA ? 0u : ((spanA < (uint32_t)STAGE_CAP ? spanA : (uint32_t)STAGE_CAP) + 15u) >> 4;
-        const uint32_t chunksB = bcastB ? 0u : ((spanB < (uint32_t)STAGE_CAP ? spanB : (uint32_t)STAGE_CAP) + 15u) >> 4;
+        // the strings of the block must lie inside the first stagedX bytes; the copy itself takes the 32 bytes behind them
+        // along when the column has them (the window of the block's last rows reaches there), and 32 zeros follow the copy --
+        // a window must never show what an earlier block left in LDS: one stale byte with its high bit set and the row would
+        // be taken for non-ASCII and left to the slow kernels
+        const uint32_t stagedA = bcastA ? 0u : (((spanA < (uint32_t)STAGE_CAP ? spanA : (uint32_t)STAGE_CAP) + 15u) & ~15u);
+        const uint32_t stagedB = bcastB ? 0u : (((spanB < (uint32_t)STAGE_CAP ? spanB : (uint32_t)STAGE_CAP) + 15u) & ~15u);
+        const uint32_t leftA = totalA - baseA + misA, leftB = totalB - baseB + misB; // column bytes from the aligned start on
+        const uint32_t chunksA = bcastA ? 0u : ((stagedA + 32u < leftA ? stagedA + 32u : leftA) + 15u) >> 4;
+        const uint32_t chunksB = bcastB ? 0u : ((stagedB + 32u < leftB ? stagedB + 32u : leftB) + 15u) >> 4;
+        if (tid < 2u) *reinterpret_cast<uint4 *>(s_bytes + (chunksA << 4) + tid * 16u) = make_uint4(0u, 0u, 0u, 0u);
+        else if (tid < 4u) *reinterpret_cast<uint4 *>(s_bytes + COLB + (chunksB << 4) + (tid - 2u) * 16u) = make_uint4(0u, 0u, 0u, 0u);
         {
             const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
 #pragma unroll
@@ -370,7 +384,6 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         // ---- C: sortA(j): lengths -> bucket keys (number of DP columns the pair will run), ranks by LDS atomics
         uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT];
         {
-            const uint32_t stagedA = chunksA << 4, stagedB = chunksB << 4;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const uint32_t i = (uint32_t)RPT * tid + (uint32_t)q;
@@ -448,12 +461,21 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         row0 = next_row0;
     }
     if (prev_rows) store_block(prev_row0, prev_rows);
+    if (publish) lds_barrier(); // (uniform) every wave's contribution to s_left is in
     if (tid == 0u) {
-        // the last workgroup to leave clears the counters for the next launch on this slot
-        const uint32_t done = atomicAdd(&sched[1], 1u);
+        // the last workgroup to leave clears the counters for the next launch on this slot; for an eager (small) call it
+        // also tells the host how many rows are left for the kernels behind this one -- usually none, and then the host
+        // launches nothing else (one launch instead of five)
+        if (publish && s_left) __hip_atomic_fetch_add(&sched[2], s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t done = __hip_atomic_fetch_add(&sched[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1u) {
+            if (publish) {
+                const uint32_t total = __hip_atomic_load(&sched[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&publish->lane_left, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sched[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #ifdef STRSIM_STAGE_STAMPS
