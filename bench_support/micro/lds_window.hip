@@ -47,6 +47,22 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, unsigned long long *clk,
             for (int j = 0; j < 4; ++j) { const u32x2_a4 a = *reinterpret_cast<const u32x2_a4 *>(q + 8 * j); t ^= a.x ^ a.y; }
             t ^= *reinterpret_cast<const uint32_t *>(q + 32);
             acc += t;
+        } else if (MODE == 6) { // two 16-byte reads + one dword at a DWORD-aligned (not 16-byte aligned) address: 9 dwords
+            const uint8_t *q = buf + (off & ~3u);
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            u32x4_a4 a, b;
+            uint32_t c;
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(c) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q) : "memory");
+            acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c;
+        } else if (MODE == 7) { // four 8-byte reads + one dword at a dword-aligned address
+            const uint8_t *q = buf + (off & ~3u);
+            typedef uint32_t u32x2_a4b __attribute__((ext_vector_type(2), aligned(4)));
+            u32x2_a4b a0, a1, a2, a3;
+            uint32_t c;
+            asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:8\n\tds_read_b64 %2, %5 offset:16\n\tds_read_b64 %3, %5 offset:24\n\tds_read_b32 %4, %5 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(c) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q) : "memory");
+            acc += a0.x ^ a0.y ^ a1.x ^ a1.y ^ a2.x ^ a2.y ^ a3.x ^ a3.y ^ c;
         } else { // two aligned 16-byte reads (the floor: what an aligned window would cost)
             const uint8_t *q = buf + (off & ~15u);
             const u32x4_a a = *reinterpret_cast<const u32x4_a *>(q), b = *reinterpret_cast<const u32x4_a *>(q + 16);
@@ -93,6 +109,8 @@ int main()
         run<3>(w, "3 x ds_read_b128, 16-byte aligned");
         run<4>(w, "4 x ds_read2_b32 + ds_read_b32, dword-aligned");
         run<5>(w, "2 x ds_read_b128, 16-byte aligned (floor)");
+        run<6>(w, "2 x ds_read_b128 + ds_read_b32, dword-aligned");
+        run<7>(w, "4 x ds_read_b64 + ds_read_b32, dword-aligned");
     }
     return 0;
 }

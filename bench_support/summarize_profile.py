@@ -17,7 +17,7 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-def traffic_json(out, key, kernel="k_lane_pairs"):
+def traffic_json(out, key, kernel="k_lane_stage"):
     """HBM bytes per launch of the dominant kernel (name contains `kernel`): FETCH_SIZE (KiB, doubled: gfx950 reports
     half of a wide coalesced read -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB), each from its own --pmc pass.
     key = "<config>:<measure>:<rows per GPU>", the key bench.py looks up."""
@@ -54,14 +54,14 @@ def traffic_json(out, key, kernel="k_lane_pairs"):
 def main():
     out = sys.argv[1]
     if len(sys.argv) > 2:
-        traffic_json(out, sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "k_lane_pairs")
+        traffic_json(out, sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "k_lane_stage")
     st = find(os.path.join(out, "trace"), "*kernel_stats.csv")
     if st:
         print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
         for r in csv.DictReader(open(st)):
             print(f'{short(r["Name"]):70s} calls={r["Calls"]:>4s} avg_us={float(r["AverageNs"])/1e3:10.1f} '
                   f'min_us={float(r["MinNs"])/1e3:10.1f} max_us={float(r["MaxNs"])/1e3:10.1f} pct={r["Percentage"]}')
-    for grp in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for grp in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_ta"):
         f = find(os.path.join(out, grp), "*counter_collection.csv")
         if not f:
             continue

@@ -196,7 +196,7 @@ k_lane_lit_lev(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ va
             // mine: a column string of <= 32 bytes inside what was staged (the window behind it may hold anything)
             bool fast = have && lit_ok && lp <= 32u && p0 + lp <= staged;
             uint32_t wp[8];
-            stage_lds32(&s_bytes[bb][fast ? p0 : 0u], wp);
+            stage_window(&s_bytes[bb][0], fast ? p0 : 0u, wp);
             uint32_t any;
             const uint32_t vary = window_vary(wt, wp, any);
             if (any & 0x80u) fast = false;

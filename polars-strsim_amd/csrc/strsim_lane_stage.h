@@ -108,6 +108,35 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // when both sides are columns.
 constexpr uint32_t STAGE_DEAD = 1u << 31;
 
+#ifndef STRSIM_STAGE_ALIGNED_WINDOWS
+#define STRSIM_STAGE_ALIGNED_WINDOWS 1 // cfg2: 1.587 ms against 1.636 ms with 0 (same box, same run)
+#endif
+// 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7].
+//   0: two ds_read_b128 at the byte address.  gfx950 serves a wide LDS read that is not naturally aligned one lane at a time
+//      (129 LDS cycles per 64-lane window, whatever the width: bench_support/micro/lds_window.hip) but it costs no VALU;
+//   1: nine dwords from the dword-aligned address below (ds_read2_b32, 56 LDS cycles) + eight v_alignbyte_b32.
+__device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, uint32_t (&w)[8])
+{
+#if STRSIM_STAGE_ALIGNED_WINDOWS
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    const uint8_t *q = base + (at & ~3u);
+    const u32x4_a4 lo = *reinterpret_cast<const u32x4_a4 *>(q);
+    const u32x4_a4 hi = *reinterpret_cast<const u32x4_a4 *>(q + 16);
+    const uint32_t top = *reinterpret_cast<const uint32_t *>(q + 32);
+    const uint32_t sh = at & 3u;
+    w[0] = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh); w[1] = __builtin_amdgcn_alignbyte(lo.z, lo.y, sh);
+    w[2] = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh); w[3] = __builtin_amdgcn_alignbyte(hi.x, lo.w, sh);
+    w[4] = __builtin_amdgcn_alignbyte(hi.y, hi.x, sh); w[5] = __builtin_amdgcn_alignbyte(hi.z, hi.y, sh);
+    w[6] = __builtin_amdgcn_alignbyte(hi.w, hi.z, sh); w[7] = __builtin_amdgcn_alignbyte(top, hi.w, sh);
+#else
+    const uint8_t *p = base + at;
+    const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
+    const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
+    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+    w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+#endif
+}
+
 __device__ __forceinline__ void stage_lds32(const uint8_t *p, uint32_t (&w)[8])
 {
     const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
@@ -443,8 +472,8 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
             if (r * 64u >= nmine) continue;
             const uint2 d = s_desc[r * 64u + lane];
             uint32_t wt[8], wp[8];
-            stage_lds32(s_bytes + (d.x & 0xFFFFu), wt);
-            stage_lds32(s_bytes + (d.x >> 16), wp);
+            stage_window(s_bytes, d.x & 0xFFFFu, wt);
+            stage_window(s_bytes, d.x >> 16, wp);
 #if defined(STRSIM_STAGE_STAMPS) || defined(STRSIM_STAGE_LGKM)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
