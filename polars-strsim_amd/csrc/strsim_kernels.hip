@@ -1818,7 +1818,7 @@ static void launch_lane_t(const LaunchArgs &a)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;
         hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
+                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
     } else {
         hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
@@ -1906,8 +1906,17 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     OutPtrs op{};
     for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
-    hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
-                       a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
+    if (a.stage_grid > 0) {
+        // one staged pass, five outputs (strsim_lane_stage.h, MEASURE = ALL_MEASURES)
+        const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
+        const uint64_t cap = (uint64_t)a.stage_grid * 4u / 5u; // 4 resident workgroups per CU
+        const uint64_t gs = nsb < cap ? nsb : cap;
+        hipLaunchKernelGGL(k_lane_stage_all, dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA,
+                           a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
+    } else {
+        hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
+                           a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
+    }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
     if (e != hipSuccess) return e;

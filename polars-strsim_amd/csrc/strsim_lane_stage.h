@@ -137,14 +137,6 @@ __device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, u
 #endif
 }
 
-__device__ __forceinline__ void stage_lds32(const uint8_t *p, uint32_t (&w)[8])
-{
-    const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
-    const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
-    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-    w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
-}
-
 // inclusive prefix sum over lanes 0..31 (and, independently, 32..63) with five DPP adds: shifts by 1, 2, 4, 8 inside the
 // rows of 16 lanes (lanes shifted in from outside a row read 0), then lane 15 of the even rows added to the odd rows
 __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
@@ -173,9 +165,86 @@ __device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint
     return code;
 }
 
+// All five measures of one pair from one set of bit-planes (BASELINE config 4), as the integers their epilogues need, packed
+// into 64 bits: dist | m << 6 | t << 12 | I << 18 | common prefix << 24 | la << 27 | lb << 33 (all-ones is never produced).
+// Jaro's matching serves Jaro and Jaro-Winkler, the multiset intersection Jaccard and Dice; no role swap (Jaro walks a, so
+// every measure does).  The epilogues run in the store phase (stage_all_epilogues), once per row, on coalesced lanes.
+template <int NP>
+__device__ __forceinline__ unsigned long long stage_all_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
+                                                             uint32_t lb, uint32_t tmin, uint32_t tmax)
+{
+    uint32_t P[NP];
+    build_planes<NP>(wb, P);
+    const bool live = la != 0u && lb != 0u;
+    const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
+    uint32_t m, t;
+    jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
+    const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
+    const uint32_t dist = lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    const uint32_t pre = common_prefix4(wa[0], la1, wb[0], lb1);
+    const uint32_t lo = dist | (m << 6) | (t << 12) | (isect << 18) | (pre << 24) | (la << 27); // la: 5 of its 6 bits fit here
+    return (unsigned long long)lo | ((unsigned long long)(la >> 5) << 32) | ((unsigned long long)lb << 33);
+}
+
+// the five f64 results of a packed row, the reference's operations in the reference's order (strsim.rs:160, :238-243,
+// :260-270, :301-306, :337-343; early-outs :128-130, :182-186, :288-292, :324-328)
+__device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, const double *__restrict__ qtab, double (&r)[5])
+{
+    const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
+    const uint32_t dist = lo & 63u, m = (lo >> 6) & 63u, t = (lo >> 12) & 63u, isect = (lo >> 18) & 63u, pre = (lo >> 24) & 7u;
+    const uint32_t la = ((lo >> 27) & 31u) | ((hi & 1u) << 5), lb = (hi >> 1) & 63u;
+    if (la == 0u || lb == 0u) {
+        const double v = (la == 0u && lb == 0u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = v;
+        return;
+    }
+    r[LEVENSHTEIN] = 1.0 - qtab[dist * (uint32_t)QTAB_N + (la > lb ? la : lb)];
+    const double j = epilogue_jaro_q(qtab, m, t, la, lb);
+    r[JARO] = j;
+    r[JARO_WINKLER] = epilogue_jaro_winkler(j, pre);
+    r[JACCARD] = epilogue_jaccard(isect, la, lb);
+    r[SORENSEN_DICE] = epilogue_sorensen_dice(isect, la, lb);
+}
+
+// One of the other four measures as 32 bits of integers: Jaro / Jaro-Winkler: m | t << 6 | la << 12 | lb << 18 | common
+// prefix << 24; Jaccard / Dice: I | la << 6 | lb << 12 (all-ones is never produced).  text = a, pattern = b.
+template <int MEASURE, int NP>
+__device__ __forceinline__ uint32_t stage_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb, uint32_t tmax)
+{
+    uint32_t P[NP];
+    build_planes<NP>(wb, P);
+    const bool live = la != 0u && lb != 0u;
+    const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
+    if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        uint32_t m, t;
+        jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
+        const uint32_t pre = MEASURE == JARO_WINKLER ? common_prefix4(wa[0], la1, wb[0], lb1) : 0u;
+        return m | (t << 6) | (la << 12) | (lb << 18) | (pre << 24);
+    }
+    const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
+    return isect | (la << 6) | (lb << 12);
+}
+
+// its f64 epilogue, the reference's operations in the reference's order (strsim.rs:238-243, :260-270, :301-306, :337-343;
+// early-outs :182-186, :288-292, :324-328)
+template <int MEASURE>
+__device__ __forceinline__ double stage_epilogue(uint32_t pk, const double *__restrict__ qtab)
+{
+    if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        const uint32_t m = pk & 63u, t = (pk >> 6) & 63u, la = (pk >> 12) & 63u, lb = (pk >> 18) & 63u, pre = (pk >> 24) & 7u;
+        if (la == 0u || lb == 0u) return (la == 0u && lb == 0u) ? 1.0 : 0.0;
+        const double j = epilogue_jaro_q(qtab, m, t, la, lb);
+        return MEASURE == JARO_WINKLER ? epilogue_jaro_winkler(j, pre) : j;
+    }
+    const uint32_t isect = pk & 63u, la = (pk >> 6) & 63u, lb = (pk >> 12) & 63u;
+    if (la == 0u || lb == 0u) return (la == 0u && lb == 0u) ? 1.0 : 0.0;
+    return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+}
+
 template <int MEASURE>
 __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta, uint16_t *s_code,
-                                              double *s_val, const double *__restrict__ qtab)
+                                              uint32_t *s_word, double *s_val)
 {
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
@@ -188,30 +257,37 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
     const uint32_t la = fast ? lt : 0u, lb = fast ? lp : 0u;
     const uint32_t tmax = wave_max_rounded(la);
     const bool wide = __ballot(fast && (vary & 0x60u)) != 0ull; // six-plane rounds run as seven (register budget)
+    // the round's rows come in bucket order (two text lengths per bucket), so its first row bounds the shortest text
+    const uint32_t lt0 = uniform(lt);
+    const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
     if (MEASURE == LEVENSHTEIN) {
-        // the round's rows come in bucket order (two text lengths per bucket), so its first row bounds the shortest text
-        const uint32_t lt0 = uniform(lt);
-        const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
         uint32_t code;
         if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmin, tmax);
         else code = stage_lev_code<5>(wt, la, wp, lb, tmin, tmax);
         if (fast) s_code[idx] = (uint16_t)code;
+    } else if (MEASURE == ALL_MEASURES) {
+        unsigned long long pk;
+        if (wide) pk = stage_all_ints<7>(wt, la, wp, lb, tmin, tmax);
+        else pk = stage_all_ints<5>(wt, la, wp, lb, tmin, tmax);
+        if (fast) reinterpret_cast<unsigned long long *>(s_val)[idx] = pk;
     } else {
-        double res;
-        if (wide) res = lane_pair_result<MEASURE, 7>(wt, la, wp, lb, tmax, nullptr, qtab);
-        else res = lane_pair_result<MEASURE, 5>(wt, la, wp, lb, tmax, nullptr, qtab);
-        if (fast) s_val[idx] = res;
+        // the measure's integers, 32 bits per row; its f64 epilogue runs in the store phase (stage_epilogue)
+        uint32_t pk;
+        if (wide) pk = stage_ints<MEASURE, 7>(wt, la, wp, lb, tmax);
+        else pk = stage_ints<MEASURE, 5>(wt, la, wp, lb, tmax);
+        if (fast) s_word[idx] = pk;
     }
 }
 
 template <int MEASURE>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_WAVES_PER_EU))) void
-k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
-             const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, double *__restrict__ out,
+__device__ __forceinline__ void
+lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
+             const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs,
              uint64_t n, unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
              const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
+    constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
@@ -221,8 +297,11 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     __shared__ uint32_t s_left;                // rows of this workgroup's blocks that stay in the mask
     __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
     __shared__ uint2 s_desc[B];
-    __shared__ uint16_t s_code[LEV ? B : 1];   // Levenshtein: table index per row, 0xFFFF = not computed here
-    __shared__ double s_val[LEV ? 1 : B];      // other measures: the f64 result, all-ones = not computed here
+    // results wait in LDS for the coalesced store phase as the integers their f64 epilogue needs (all-ones = the row was not
+    // computed here): Levenshtein a 16-bit table index, the other measures 32 bits, the five-output pass 64
+    __shared__ uint16_t s_code[LEV ? B : 1];
+    __shared__ uint32_t s_word[(!LEV && !ALL) ? B : 1];
+    __shared__ double s_val[ALL ? B : 1];
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
@@ -233,7 +312,8 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     for (int q = 0; q < RPT; ++q) {
         const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
         if (LEV) s_code[i] = 0xFFFFu;
-        else reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;
+        else if (ALL) reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;
+        else s_word[i] = 0xFFFFFFFFu;
     }
 
     const uint32_t totalA = load_invariant(offA + rowsA), totalB = load_invariant(offB + rowsB);
@@ -318,15 +398,19 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
 
     // store(j-1): staged results -> global, coalesced; rows nobody computed go into the mask word of their chunk
     auto store_block = [&](uint64_t r0, uint32_t rows) {
-        double *__restrict__ const outb = out + r0;
         unsigned long long *__restrict__ const maskb = slowmask + (r0 >> 6);
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
             if ((uint32_t)q * STAGE_BLOCK < rows) { // (uniform)
                 bool undone;
-                double v;
-                if (LEV) {
+                double v = 0.0, v5[5];
+                if (ALL) {
+                    const unsigned long long pk = reinterpret_cast<const unsigned long long *>(s_val)[i];
+                    reinterpret_cast<unsigned long long *>(s_val)[i] = ~0ull;
+                    undone = pk == ~0ull;
+                    if (!undone) stage_all_epilogues(pk, qtab, v5);
+                } else if (LEV) {
                     const uint32_t code = s_code[i];
                     s_code[i] = 0xFFFFu;
                     undone = code == 0xFFFFu;
@@ -335,13 +419,22 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
                     // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
                     v = 1.0 - qtab[undone ? 0u : code];
                 } else {
-                    v = s_val[i];
-                    reinterpret_cast<unsigned long long *>(&s_val[i])[0] = ~0ull;
-                    undone = (uint32_t)(__double_as_longlong(v) >> 32) == 0xFFFFFFFFu;
+                    const uint32_t pk = s_word[i];
+                    s_word[i] = 0xFFFFFFFFu;
+                    undone = pk == 0xFFFFFFFFu;
+                    constexpr int M1 = (MEASURE == ALL_MEASURES || MEASURE == LEVENSHTEIN) ? JARO : MEASURE;
+                    if (!undone) v = stage_epilogue<M1>(pk, qtab);
                 }
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
-                if (valid && !undone) outb[i] = v;
+                if (valid && !undone) {
+                    if (ALL) {
+#pragma unroll
+                        for (int o = 0; o < 5; ++o) outs.p[o][r0 + i] = v5[o];
+                    } else {
+                        outs.p[0][r0 + i] = v;
+                    }
+                }
                 if (lane == 0u && valid) {
                     maskb[i >> 6] = left;
                     if (publish && left) atomicAdd(&s_left, (uint32_t)__builtin_popcountll(left));
@@ -478,7 +571,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             STAGE_STAMP(7);
-            stage_compute<MEASURE>(wt, wp, d.y, s_code, s_val, qtab);
+            stage_compute<MEASURE>(wt, wp, d.y, s_code, s_word, s_val);
             STAGE_STAMP(8);
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
@@ -520,4 +613,28 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
         g_stage_stamps[w][15] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
     }
 #endif
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_WAVES_PER_EU))) void
+k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
+             const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
+             unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
+             uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
+{
+    lane_stage_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish);
+}
+
+// The five-output instantiation keeps the matching state of three cores alive at once: its own register budget
+// (4 waves per SIMD; its 33 KB of LDS admit 4 workgroups per CU anyway).
+#ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
+#define STRSIM_STAGE_ALL_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_ALL_WAVES_PER_EU))) void
+k_lane_stage_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
+                 const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
+                 unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
+                 uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
+{
+    lane_stage_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish);
 }
