@@ -274,7 +274,7 @@ def main():
             pass
         # the dominant kernel: k_lane_pairs, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
         # k_wave_pairs, timed together by the second event pair) takes longer -- cfg3 and cfg5
-        dom_ms, dom_name = lane_ms, ("k_lane_stage<%s>" if len(measures) == 1 else "k_lane_pairs_all (five outputs)%s") % (measures[0] if len(measures) == 1 else "")
+        dom_ms, dom_name = lane_ms, ("k_lane_stage<%s>" if len(measures) == 1 else "k_lane_stage_all (five outputs)%s") % (measures[0] if len(measures) == 1 else "")
         if wave_ms > lane_ms:
             dom_ms = wave_ms
             dom_name = ("k_wave_pairs<%s>" if (a.config == "cfg5" or hi > 128) else "k_lane_wide<%s> (+ k_lane_utf8, k_wave_pairs)") % measures[0]
