@@ -258,16 +258,43 @@ STRSIM_HD uint32_t twice(uint32_t x)
 #endif
 }
 
+#ifndef STRSIM_LEV_FREEZE
+#define STRSIM_LEV_FREEZE 1
+#endif
 template <int NP>
 STRSIM_HD uint32_t lev_myers32_snap(const uint32_t (&wt)[8], uint32_t lt, uint32_t tmin, uint32_t tmax, const uint32_t (&P)[NP],
                                     uint32_t lp)
 {
-    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u, sP = 0u, sM = 0u;
+    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
+#if !STRSIM_LEV_FREEZE
+    uint32_t sP = 0u, sM = 0u;
+#endif
 #pragma unroll
     for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
         if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
         // one straight-line block per group of columns (the match masks of the whole group are independent work the
-        // scheduler can put between the dependent steps of the recurrence), the copies behind it under one uniform test
+        // scheduler can put between the dependent steps of the recurrence)
+#if STRSIM_LEV_FREEZE
+        // A lane whose text has ended keeps its (Pv, Mv): in the groups where that can happen (from tmin on) every column
+        // runs under `column < lt` -- one compare per column and the exec mask, instead of copying the state aside.
+        auto column = [&](int j) {
+            const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wt[j >> 2], j & 3);
+            const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
+            const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
+            const uint32_t nX = twice(nHP);                                 // ~((HP << 1) | 1)
+            const uint32_t HN2 = twice(D0 & Pv);                            // HN << 1
+            Pv = bitop3<0xF2>(HN2, D0, nX);                                 // (HN << 1) | ~(D0 | X)
+            Mv = bitop3<0x50>(D0, D0, nX);                                  // D0 & X
+        };
+        if ((uint32_t)(COLS_PER_TEST * (g + 1)) >= tmin) {                 // (uniform) some lane's text may end in this group
+#pragma unroll
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj)
+                if ((uint32_t)(COLS_PER_TEST * g + jj) < lt) column(COLS_PER_TEST * g + jj);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj) column(COLS_PER_TEST * g + jj);
+        }
+#else
         uint32_t Pc[COLS_PER_TEST], Mc[COLS_PER_TEST];
 #pragma unroll
         for (int jj = 0; jj < COLS_PER_TEST; ++jj) {
@@ -290,9 +317,14 @@ STRSIM_HD uint32_t lev_myers32_snap(const uint32_t (&wt)[8], uint32_t lt, uint32
                 sM = bitop3<0xCA>(here, Mc[jj], sM);
             }
         }
+#endif
     }
     const uint32_t rows = low_ones(lp);
+#if STRSIM_LEV_FREEZE
+    return lt + popc32(Pv & rows) - popc32(Mv & rows);
+#else
     return lt + popc32(sP & rows) - popc32(sM & rows);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,6 +40,10 @@
 #define STRSIM_STAGE_BUCKET_SHIFT 1
 #endif
 
+#ifndef STRSIM_STAGE_STORE_FIRST
+#define STRSIM_STAGE_STORE_FIRST 1
+#endif
+
 #ifdef STRSIM_STAGE_STAMPS
 // diagnostic build only (never in the product library): per-wave cycle sums of the phases of k_lane_stage, read back with
 // strsim_debug_stage_stamps().  [0] block cut + bytes DMA issue [1] store [2] sortA [3] barrier [4] sortB [5] DMA wait +
@@ -187,11 +191,12 @@ __device__ __forceinline__ unsigned long long stage_all_ints(const uint32_t (&wa
 }
 
 // the five f64 results of a packed row, the reference's operations in the reference's order (strsim.rs:160, :238-243,
-// :260-270, :301-306, :337-343; early-outs :128-130, :182-186, :288-292, :324-328)
-__device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, const double *__restrict__ qtab, double (&r)[5])
+// :260-270, :301-306, :337-343; early-outs :128-130, :182-186, :288-292, :324-328).  qa, qb, qc, qd: the integer quotients
+// m / la, m / lb, (m - t / 2) / m and dist / max(la, lb) from the context's table (loaded by the caller, all rows at once).
+__device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, double qa, double qb, double qc, double qd, double (&r)[5])
 {
     const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
-    const uint32_t dist = lo & 63u, m = (lo >> 6) & 63u, t = (lo >> 12) & 63u, isect = (lo >> 18) & 63u, pre = (lo >> 24) & 7u;
+    const uint32_t m = (lo >> 6) & 63u, isect = (lo >> 18) & 63u, pre = (lo >> 24) & 7u;
     const uint32_t la = ((lo >> 27) & 31u) | ((hi & 1u) << 5), lb = (hi >> 1) & 63u;
     if (la == 0u || lb == 0u) {
         const double v = (la == 0u && lb == 0u) ? 1.0 : 0.0;
@@ -199,8 +204,8 @@ __device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, const
         for (int q = 0; q < 5; ++q) r[q] = v;
         return;
     }
-    r[LEVENSHTEIN] = 1.0 - qtab[dist * (uint32_t)QTAB_N + (la > lb ? la : lb)];
-    const double j = epilogue_jaro_q(qtab, m, t, la, lb);
+    r[LEVENSHTEIN] = 1.0 - qd;
+    const double j = m == 0u ? 0.0 : (qa + qb + qc) / 3.0; // (strsim.rs:238-243)
     r[JARO] = j;
     r[JARO_WINKLER] = epilogue_jaro_winkler(j, pre);
     r[JACCARD] = epilogue_jaccard(isect, la, lb);
@@ -227,14 +232,14 @@ __device__ __forceinline__ uint32_t stage_ints(const uint32_t (&wa)[8], uint32_t
 }
 
 // its f64 epilogue, the reference's operations in the reference's order (strsim.rs:238-243, :260-270, :301-306, :337-343;
-// early-outs :182-186, :288-292, :324-328)
+// early-outs :182-186, :288-292, :324-328).  qa, qb, qc: m / la, m / lb, (m - t / 2) / m from the table (Jaro, Jaro-Winkler).
 template <int MEASURE>
-__device__ __forceinline__ double stage_epilogue(uint32_t pk, const double *__restrict__ qtab)
+__device__ __forceinline__ double stage_epilogue(uint32_t pk, double qa, double qb, double qc)
 {
     if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
-        const uint32_t m = pk & 63u, t = (pk >> 6) & 63u, la = (pk >> 12) & 63u, lb = (pk >> 18) & 63u, pre = (pk >> 24) & 7u;
+        const uint32_t m = pk & 63u, la = (pk >> 12) & 63u, lb = (pk >> 18) & 63u, pre = (pk >> 24) & 7u;
         if (la == 0u || lb == 0u) return (la == 0u && lb == 0u) ? 1.0 : 0.0;
-        const double j = epilogue_jaro_q(qtab, m, t, la, lb);
+        const double j = m == 0u ? 0.0 : (qa + qb + qc) / 3.0;
         return MEASURE == JARO_WINKLER ? epilogue_jaro_winkler(j, pre) : j;
     }
     const uint32_t isect = pk & 63u, la = (pk >> 6) & 63u, lb = (pk >> 12) & 63u;
@@ -262,8 +267,21 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
     const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
     if (MEASURE == LEVENSHTEIN) {
         uint32_t code;
+#if defined(STRSIM_EXP_NOCORE)   // diagnostic builds only: everything but the cores / the cores twice
+        code = (la + tmin + tmax + (wide ? 1u : 0u)) * (uint32_t)QTAB_N + lb;
+#else
         if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmin, tmax);
         else code = stage_lev_code<5>(wt, la, wp, lb, tmin, tmax);
+#if defined(STRSIM_EXP_CORE2X)
+        {
+            uint32_t wt2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wt2[q] = wt[q] ^ (code >> 31);
+            if (wide) code = stage_lev_code<7>(wt2, la, wp, lb, tmin, tmax);
+            else code = stage_lev_code<5>(wt2, la, wp, lb, tmin, tmax);
+        }
+#endif
+#endif
         if (fast) s_code[idx] = (uint16_t)code;
     } else if (MEASURE == ALL_MEASURES) {
         unsigned long long pk;
@@ -396,9 +414,61 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
-    // store(j-1): staged results -> global, coalesced; rows nobody computed go into the mask word of their chunk
+    // store(j-1): staged results -> global, coalesced; rows nobody computed go into the mask word of their chunk.
+    // Three straight-line passes -- staged integers out of LDS, every table load of every row of the thread, then the
+    // arithmetic and the stores: left to itself hipcc sinks each load into the branch that stores its row and waits for it
+    // there (s_waitcnt vmcnt(0) per row: the L2 round trips of a thread's rows one after the other, each behind the previous
+    // row's store).  `pin` keeps a loaded value outside those branches.
+    auto pin = [](double &x) { asm volatile("" : "+v"(x)); };
     auto store_block = [&](uint64_t r0, uint32_t rows) {
         unsigned long long *__restrict__ const maskb = slowmask + (r0 >> 6);
+        constexpr int M1 = (MEASURE == ALL_MEASURES || MEASURE == LEVENSHTEIN) ? JARO : MEASURE;
+        constexpr bool JARO_LIKE = ALL || M1 == JARO || M1 == JARO_WINKLER;
+        unsigned long long pk[RPT]; // (rows of the block behind `rows` hold all-ones: nobody computed them)
+        double t0[RPT], t1[RPT], t2[RPT], t3[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
+            if (ALL) {
+                pk[q] = reinterpret_cast<const unsigned long long *>(s_val)[i];
+                reinterpret_cast<unsigned long long *>(s_val)[i] = ~0ull;
+            } else if (LEV) {
+                pk[q] = s_code[i];
+                s_code[i] = 0xFFFFu;
+            } else {
+                pk[q] = s_word[i];
+                s_word[i] = 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            // the table entries the row's epilogue needs; an all-ones (not computed) row reads valid entries too
+            if (LEV) {
+                // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
+                // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
+                // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
+                t0[q] = qtab[(uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q]];
+            } else if (JARO_LIKE) {
+                const uint32_t lo = (uint32_t)pk[q], hi = (uint32_t)(pk[q] >> 32);
+                const uint32_t m = (lo >> (ALL ? 6 : 0)) & 63u, t = (lo >> (ALL ? 12 : 6)) & 63u;
+                const uint32_t la = ALL ? (((lo >> 27) & 31u) | ((hi & 1u) << 5)) : ((lo >> 12) & 63u);
+                const uint32_t lb = ALL ? ((hi >> 1) & 63u) : ((lo >> 18) & 63u);
+                const uint32_t h = t >> 1;
+                t0[q] = qtab[m * (uint32_t)QTAB_N + la];
+                t1[q] = qtab[m * (uint32_t)QTAB_N + lb];
+                t2[q] = qtab[(m > h ? m - h : 0u) * (uint32_t)QTAB_N + m];
+                if (ALL) {
+                    const uint32_t dist = lo & 63u;
+                    t3[q] = qtab[dist * (uint32_t)QTAB_N + (la > lb ? la : lb)];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (LEV || JARO_LIKE) pin(t0[q]);
+            if (JARO_LIKE) { pin(t1[q]); pin(t2[q]); }
+            if (ALL) pin(t3[q]);
+        }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const uint32_t i = (uint32_t)q * STAGE_BLOCK + tid;
@@ -406,27 +476,21 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 bool undone;
                 double v = 0.0, v5[5];
                 if (ALL) {
-                    const unsigned long long pk = reinterpret_cast<const unsigned long long *>(s_val)[i];
-                    reinterpret_cast<unsigned long long *>(s_val)[i] = ~0ull;
-                    undone = pk == ~0ull;
-                    if (!undone) stage_all_epilogues(pk, qtab, v5);
+                    undone = pk[q] == ~0ull;
+                    if (!undone) stage_all_epilogues(pk[q], t0[q], t1[q], t2[q], t3[q], v5);
                 } else if (LEV) {
-                    const uint32_t code = s_code[i];
-                    s_code[i] = 0xFFFFu;
-                    undone = code == 0xFFFFu;
-                    // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
-                    // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
-                    // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
-                    v = 1.0 - qtab[undone ? 0u : code];
+                    undone = (uint32_t)pk[q] == 0xFFFFu;
+                    v = 1.0 - t0[q];
                 } else {
-                    const uint32_t pk = s_word[i];
-                    s_word[i] = 0xFFFFFFFFu;
-                    undone = pk == 0xFFFFFFFFu;
-                    constexpr int M1 = (MEASURE == ALL_MEASURES || MEASURE == LEVENSHTEIN) ? JARO : MEASURE;
-                    if (!undone) v = stage_epilogue<M1>(pk, qtab);
+                    undone = (uint32_t)pk[q] == 0xFFFFFFFFu;
+                    if (!undone) v = stage_epilogue<M1>((uint32_t)pk[q], t0[q], t1[q], t2[q]);
                 }
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
+#ifdef STRSIM_EXP_NOSTORE
+                if (valid && !undone && v == 12345.0) outs.p[0][r0 + i] = v;
+                if (lane == 0u && valid && left == 0x1234ull) {
+#else
                 if (valid && !undone) {
                     if (ALL) {
 #pragma unroll
@@ -436,6 +500,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                     }
                 }
                 if (lane == 0u && valid) {
+#endif
                     maskb[i >> 6] = left;
                     if (publish && left) atomicAdd(&s_left, (uint32_t)__builtin_popcountll(left));
                 }
@@ -456,6 +521,12 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             }
             grab_pending = false;
         }
+#if STRSIM_STAGE_STORE_FIRST
+        // ---- B: store(j-1).  Before the bytes DMA of this block is issued: a wave's vector-memory results return in order,
+        //         so the table loads of the store phase would otherwise sit behind its share of the DMA (HBM latency).
+        if (prev_rows) store_block(prev_row0, prev_rows);
+        STAGE_STAMP(1);
+#endif
         // ---- the block: as many of the next 64-row chunks (at most B / 64) as have their bytes inside the staging areas
         const uint32_t avail = (uint32_t)(row_end - row0 < (uint64_t)B ? row_end - row0 : (uint64_t)B); // rows whose offsets are in s_off
         const uint32_t baseA = bcastA ? litA0 : uniform(s_off[0][0]), baseB = bcastB ? litB0 : uniform(s_off[1][0]);
@@ -493,16 +564,24 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
 #pragma unroll
             for (int it = 0; it < STAGE_DMA_ITERS; ++it) {
+#ifdef STRSIM_EXP_NOBYTES
+                if (chunksA == 0x12345u)
+#endif
                 if (tid + (uint32_t)it * STAGE_BLOCK < chunksA)
                     lds_dma_b128(gA + 16 * it * STAGE_BLOCK, tid16, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+#ifdef STRSIM_EXP_NOBYTES
+                if (chunksA == 0x12345u)
+#endif
                 if (tid + (uint32_t)it * STAGE_BLOCK < chunksB)
                     lds_dma_b128(gB + 16 * it * STAGE_BLOCK, tid16, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
             }
         }
         STAGE_STAMP(0);
+#if !STRSIM_STAGE_STORE_FIRST
         // ---- B: store(j-1)
         if (prev_rows) store_block(prev_row0, prev_rows);
         STAGE_STAMP(1);
+#endif
         // ---- C: sortA(j): lengths -> bucket keys (number of DP columns the pair will run), ranks by LDS atomics
         uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT];
         {
@@ -521,7 +600,11 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
                 const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
                 skey[q] = key;
+#ifdef STRSIM_EXP_NOSORT
+                srank[q] = i; skey[q] = 0u;
+#else
                 srank[q] = atomicAdd(&s_cnt[key], 1u);
+#endif
                 sd0[q] = mine ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
                 sd1[q] = mine ? (lt | (lp << 8) | (i << 16)) : STAGE_DEAD;
             }
@@ -562,7 +645,14 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #pragma unroll 1
         for (int k = 0; k < STAGE_RPW; ++k) {
             const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+#ifdef STRSIM_EXP_NOSORT
+            if (r * 64u >= rows) continue;
+#else
             if (r * 64u >= nmine) continue;
+#endif
+#ifdef STRSIM_EXP_NOROUNDS
+            if (nmine != 0x12345u) continue;
+#endif
             const uint2 d = s_desc[r * 64u + lane];
             uint32_t wt[8], wp[8];
             stage_window(s_bytes, d.x & 0xFFFFu, wt);
