@@ -146,11 +146,20 @@ STRSIM_API int strsim_ctx_timing_enable(strsim_ctx_t *ctx, int enable);
 STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms, uint64_t *lane_kernel_launches,
                            double *wave_kernel_ms, uint64_t *wave_kernel_launches);
 
+/* For a caller that keeps several calls in flight on the context's stream and learns of their completion by its own means
+ * (an event recorded on strsim_ctx_stream() behind each call): retire the OLDEST pending call only -- what
+ * strsim_ctx_synchronize() does for all of them, without waiting for the younger ones.  The caller guarantees that the
+ * oldest call's kernels have completed.  If that call held strings longer than STRSIM_WAVE_PATH_MAX_BYTES, their second
+ * pass is launched and waited for here (strsim_ctx_last_long_rows() tells).  Reference counterpart: none -- the reference's
+ * rayon loop (strsim.rs:72-100) has no device queue; this is what lets the plugin overlap H2D of slice k+1, the kernels of
+ * slice k and the D2H of slice k-1. */
+STRSIM_API int strsim_ctx_retire_oldest(strsim_ctx_t *ctx);
+
 /* Rows the last completed strsim_pairs_device() on this context routed to the wave-per-pair kernel
  * (valid after strsim_ctx_synchronize()). */
 STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
 
-/* Rows of the calls retired by the last strsim_ctx_synchronize() that held a string longer than
+/* Rows of the calls retired by the last strsim_ctx_synchronize() / strsim_ctx_retire_oldest() that held a string longer than
  * STRSIM_WAVE_PATH_MAX_BYTES: their results were written by the second pass that synchronize runs, i.e. AFTER anything
  * the caller enqueued on the stream behind the call (a caller that copies results out early re-copies when > 0). */
 STRSIM_API uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *ctx);

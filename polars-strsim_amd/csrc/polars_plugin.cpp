@@ -207,10 +207,73 @@ struct InputGuard { // the callee owns the inputs: release every array, then eve
 };
 
 // ---- output construction ---------------------------------------------------------------------------
+// Large result columns are handed to the engine in PINNED host memory from a process-wide pool: the device-to-host copy of
+// every slice lands in the column itself, so the host never copies the results (80 MB of memcpy + first-touch page faults per
+// 10 M rows -- with the packing that was all the CPU time of a call, and the CPU quota, not PCIe, is what bounds a call).  The
+// Arrow release callback returns the block to the pool.  Pinned memory is a limited resource and the engine may keep a
+// column for as long as it likes, so: only columns of PINNED_OUT_MIN_BYTES .. PINNED_OUT_MAX_BYTES, at most
+// PINNED_OUT_LENT_BYTES lent out at a time (beyond that: malloc + copy, as for small columns), at most
+// PINNED_OUT_CACHE_BYTES kept idle.  POLARS_STRSIM_PINNED_OUT=0 switches it off.
+constexpr size_t PINNED_OUT_MIN_BYTES = size_t(8) << 20, PINNED_OUT_MAX_BYTES = size_t(1) << 30;
+constexpr size_t PINNED_OUT_LENT_BYTES = size_t(4) << 30, PINNED_OUT_CACHE_BYTES = size_t(1) << 30;
+class PinnedPool {
+  public:
+    void *acquire(size_t bytes)
+    {
+        static const bool off = [] { const char *e = getenv("POLARS_STRSIM_PINNED_OUT"); return e && atoi(e) == 0; }();
+        if (off || bytes < PINNED_OUT_MIN_BYTES || bytes > PINNED_OUT_MAX_BYTES) return nullptr;
+        std::lock_guard<std::mutex> lk(m_);
+        if (lent_ + bytes > PINNED_OUT_LENT_BYTES) return nullptr;
+        int best = -1;
+        for (size_t i = 0; i < blocks_.size(); ++i)
+            if (!blocks_[i].lent && blocks_[i].cap >= bytes && blocks_[i].cap <= 2 * bytes &&
+                (best < 0 || blocks_[i].cap < blocks_[(size_t)best].cap))
+                best = (int)i;
+        if (best < 0) {
+            void *p = nullptr;
+            const size_t cap = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+            // portable: every device's copy engine may write into it (one call's rows shard over the GPUs)
+            if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            blocks_.push_back(Block{p, cap, false});
+            best = (int)blocks_.size() - 1;
+        } else {
+            idle_ -= blocks_[(size_t)best].cap;
+        }
+        blocks_[(size_t)best].lent = true;
+        lent_ += blocks_[(size_t)best].cap;
+        return blocks_[(size_t)best].p;
+    }
+    void release(void *p)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        for (size_t i = 0; i < blocks_.size(); ++i) {
+            if (blocks_[i].p != p) continue;
+            lent_ -= blocks_[i].cap;
+            if (idle_ + blocks_[i].cap > PINNED_OUT_CACHE_BYTES) {
+                (void)hipHostFree(p);
+                blocks_.erase(blocks_.begin() + (long)i);
+            } else {
+                blocks_[i].lent = false;
+                idle_ += blocks_[i].cap;
+            }
+            return;
+        }
+    }
+
+  private:
+    struct Block { void *p; size_t cap; bool lent; };
+    std::mutex m_;
+    std::vector<Block> blocks_;
+    size_t lent_ = 0, idle_ = 0;
+};
+// (never destroyed: a column may be released after static destructors have begun, and the runtime unmaps pinned memory at exit)
+PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool; return *p; }
+
 struct ArrayPriv {
     void *data;
     void *validity;
     const void *bufs[2];
+    bool data_pinned; // data came from pinned_pool()
 };
 
 void release_f64_array(ArrowArray *a)
@@ -218,7 +281,7 @@ void release_f64_array(ArrowArray *a)
     if (!a || !a->release) return;
     ArrayPriv *p = static_cast<ArrayPriv *>(a->private_data);
     if (p) {
-        free(p->data);
+        if (p->data_pinned) pinned_pool().release(p->data); else free(p->data);
         free(p->validity);
         delete p;
     }
@@ -292,6 +355,9 @@ void *alloc64(size_t bytes)
 }
 
 // ---- a small persistent fork-join pool for the host-side packing (one per calling thread) ------------------
+// A call runs a dozen short jobs back to back (sizes and bytes of every slice), so an idle worker spins on the job counter for
+// a moment before it sleeps on the condition variable, and the caller spins for the stragglers the same way: waking 15
+// sleeping threads costs 30-50 us per job otherwise -- a millisecond per 10 M-row call.
 class ForkJoinPool {
   public:
     ~ForkJoinPool()
@@ -300,6 +366,7 @@ class ForkJoinPool {
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
         }
+        stop_a_.store(true, std::memory_order_release);
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
@@ -312,22 +379,40 @@ class ForkJoinPool {
             th_.emplace_back([this, id] { worker(id); });
         }
         err_.clear();
+        pending_.store(n - 1, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &fn;
             njob_ = n;
-            pending_ = n - 1;
             ++gen_;
+            gen_a_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         call(fn, 0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        job_ = nullptr;
+        if (!spin_until([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = nullptr;
+        }
         if (!err_.empty()) fail(err_);
     }
 
   private:
+    static constexpr int SPIN_US = 150;
+    template <class Pred> static bool spin_until(Pred pred)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (pred()) return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) return pred();
+        }
+    }
     void call(const std::function<void(unsigned)> &fn, unsigned t)
     {
         try {
@@ -344,6 +429,7 @@ class ForkJoinPool {
     {
         uint64_t seen = 0;
         for (;;) {
+            (void)spin_until([&] { return gen_a_.load(std::memory_order_acquire) != seen || stop_a_.load(std::memory_order_acquire); });
             const std::function<void(unsigned)> *job;
             {
                 std::unique_lock<std::mutex> lk(m_);
@@ -354,20 +440,22 @@ class ForkJoinPool {
                 job = job_;
             }
             call(*job, id);
-            {
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m_);
-                --pending_;
+                done_.notify_one();
             }
-            done_.notify_one();
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_, done_;
     const std::function<void(unsigned)> *job_ = nullptr;
-    unsigned njob_ = 0, pending_ = 0;
+    unsigned njob_ = 0;
+    std::atomic<unsigned> pending_{0};
     uint64_t gen_ = 0;
+    std::atomic<uint64_t> gen_a_{0};
     bool stop_ = false;
+    std::atomic<bool> stop_a_{false};
     std::string err_;
 };
 thread_local ForkJoinPool g_pool;
@@ -406,21 +494,31 @@ struct Slot {
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
     bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
+    hipEvent_t ev_kernels = nullptr, ev_results = nullptr; // behind the slice's kernels (compute stream) / its D2H (copy stream)
     Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; } d_out.device = true; }
-    void release() { for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); } h_out.release(); d_out.release(); }
+    void release()
+    {
+        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); }
+        h_out.release(); d_out.release();
+        if (ev_kernels) (void)hipEventDestroy(ev_kernels);
+        if (ev_results) (void)hipEventDestroy(ev_results);
+        ev_kernels = ev_results = nullptr;
+    }
 };
 
 // ---- device context per calling thread (Polars may call from several of its threads at once) -------
 struct ThreadCtx {
     strsim_ctx_t *ctx = nullptr;
     int device = 0;
-    Slot slot[2];
+    Slot slot[3];             // two slices in flight on the GPU + the one being packed
+    hipStream_t d2h = nullptr; // results travel back on their own stream: D2H of slice k runs beside H2D of slice k+1
     Buf lit_off, lit_val;     // device copy of a literal side
     Buf lit_h_off, lit_h_val; // its pinned host staging
     ~ThreadCtx()
     {
         if (ctx) {
             (void)hipSetDevice(device);
+            if (d2h) (void)hipStreamDestroy(d2h);
             for (auto &s : slot) s.release();
             lit_off.release(); lit_val.release();
             lit_h_off.release(); lit_h_val.release();
@@ -432,6 +530,8 @@ struct ThreadCtx {
     {
         if (ctx && dev != device) {
             (void)hipSetDevice(device);
+            if (d2h) (void)hipStreamDestroy(d2h);
+            d2h = nullptr;
             for (auto &s : slot) s.release();
             lit_off.release(); lit_val.release();
             lit_h_off.release(); lit_h_val.release();
@@ -444,6 +544,7 @@ struct ThreadCtx {
             lit_off.device = lit_val.device = true;
         }
         HIP_OR_FAIL(hipSetDevice(device));
+        if (!d2h) HIP_OR_FAIL(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
         return ctx;
     }
 };
@@ -505,11 +606,34 @@ void *mapped(void *pinned)
 constexpr uint64_t SLICE_ROWS = 2u << 20;                      // rows packed / shipped / computed per pipeline step
 constexpr uint64_t SLICE_BYTES = (1ull << 32) - (1ull << 24);  // packed values per slice and column (u32 offsets)
 
+// CPUs this process may keep busy: the logical CPUs, or the cgroup v2 / v1 CPU quota when that is lower (a container with a
+// 16-CPU quota on a 256-thread host: 32 packing threads there only buy throttling)
+unsigned cpu_quota()
+{
+    unsigned n = std::max<unsigned>(std::thread::hardware_concurrency(), 1u);
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 0;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 unsigned pack_threads(bool engine_parallel, uint64_t rows)
 {
     // CallerContext PARALLEL (reference strsim.rs:53): the engine is already parallel -> no helper threads here
     if (engine_parallel || rows < 32768) return 1;
-    unsigned cap = std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 1u), 32u);
+    static const unsigned granted = cpu_quota(); // logical CPUs, capped by the cgroup's CPU quota (containers)
+    unsigned cap = std::min<unsigned>(granted, 32u);
     if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) cap = std::max(1, atoi(e)); // explicit override, any value
     return (unsigned)std::min<uint64_t>(cap, rows / 16384);
 }
@@ -533,6 +657,34 @@ uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &va
     return total;
 }
 
+// the same for BOTH columns of a slice in two jobs instead of four (sizes of both, then bytes of both): thread t takes rows
+// lo(t) .. lo(t+1) of each column.  bytes[s] = packed byte count; false when a column's bytes exceed SLICE_BYTES.
+bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Buf (&off)[2], Buf (&val)[2], uint64_t (&bytes)[2], unsigned T)
+{
+    const uint64_t rows = r1 - r0;
+    T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(rows / 16384, 1));
+    std::vector<uint64_t> part[2] = {std::vector<uint64_t>(T + 1, 0), std::vector<uint64_t>(T + 1, 0)};
+    auto lo = [&](unsigned t) { return r0 + rows * t / T; };
+    fork_join(T, [&](unsigned t) { for (int s = 0; s < 2; ++s) part[s][t + 1] = range_bytes(col[s], lo(t), lo(t + 1)); });
+    for (int s = 0; s < 2; ++s) {
+        for (unsigned t = 0; t < T; ++t) part[s][t + 1] += part[s][t];
+        bytes[s] = part[s][T];
+    }
+    if (bytes[0] > SLICE_BYTES || bytes[1] > SLICE_BYTES) return false;
+    uint32_t *o[2];
+    for (int s = 0; s < 2; ++s) {
+        off[s].reserve((rows + 1) * sizeof(uint32_t));
+        val[s].reserve(bytes[s] + 64);
+        o[s] = static_cast<uint32_t *>(off[s].p);
+        o[s][0] = 0;
+    }
+    fork_join(T, [&](unsigned t) {
+        for (int s = 0; s < 2; ++s)
+            pack_range(col[s], lo(t), lo(t + 1), o[s] + (lo(t) - r0), part[s][t], part[s][t + 1], static_cast<uint8_t *>(val[s].p));
+    });
+    return true;
+}
+
 struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin call on stderr
     bool on;
     double t_pack = 0, t_wait = 0, t_d2h = 0, t_copy = 0, t_launch = 0;
@@ -542,10 +694,20 @@ struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin
     void stop(double &acc) { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// a row-count tuning knob from the environment (unset, empty or 0: the default)
+uint64_t env_rows(const char *name, uint64_t dflt)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const unsigned long long v = strtoull(e, nullptr, 10);
+    return v ? (uint64_t)v : dflt;
+}
+
 // One device's share of a call: rows [lo, hi) of the output through this thread's context on `device` (a two-slot pipeline:
-// pack slice k+1 on the host while the GPU has slice k), results straight into out[lo .. hi).
-void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t lo, uint64_t hi, double *out, unsigned T,
-               bool direct_call, int device, PhaseTimer &tm)
+// pack slice k+1 on the host while the GPU has slice k), results straight into out[lo .. hi) -- by the copy engine itself when
+// the output column is pinned memory (out_pinned), else through the slot's pinned result buffer and a host copy.
+void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t lo, uint64_t hi, double *out, bool out_pinned,
+               unsigned T, bool direct_call, int device, PhaseTimer &tm)
 {
     strsim_ctx_t *ctx = g_ctx.get(device);
     hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
@@ -576,10 +738,14 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         uint64_t rows = std::min<uint64_t>(want, hi - r0);
         for (;;) {
             bool fits = true;
-            for (int s = 0; s < 2 && fits; ++s) {
-                if (lit[s]) continue;
-                sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
-                fits = sl.bytes[s] <= SLICE_BYTES;
+            if (!lit[0] && !lit[1]) {
+                fits = pack_slice2(col, r0, r0 + rows, sl.h_off, sl.h_val, sl.bytes, T);
+            } else {
+                for (int s = 0; s < 2 && fits; ++s) {
+                    if (lit[s]) continue;
+                    sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
+                    fits = sl.bytes[s] <= SLICE_BYTES;
+                }
             }
             if (fits) break;
             if (rows == 1) fail("a single string exceeds the 4 GiB limit");
@@ -610,28 +776,44 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
             doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
             dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
         }
-        sl.h_out.reserve(sl.rows * sizeof(double));
+        const bool via_slot = sl.direct || !out_pinned; // results pass through the slot's pinned buffer
+        if (via_slot) sl.h_out.reserve(sl.rows * sizeof(double));
         if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
         double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
         // (a slice computed in place is a small call: one launch when the lane kernel leaves nothing behind)
         if ((sl.direct ? strsim_pairs_device_small : strsim_pairs_device)(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
             fail(strsim_last_error_message());
-        // results come back right behind the kernels (no separate round trip later)
-        if (!sl.direct)
-            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (!sl.direct) {
+            // results come back right behind the kernels, on the copy stream: the next slice's H2D does not queue behind them
+            if (!sl.ev_kernels) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_kernels, hipEventDisableTiming));
+            if (!sl.ev_results) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_results, hipEventDisableTiming));
+            HIP_OR_FAIL(hipEventRecord(sl.ev_kernels, stream));
+            HIP_OR_FAIL(hipStreamWaitEvent(g_ctx.d2h, sl.ev_kernels, 0));
+            HIP_OR_FAIL(hipMemcpyAsync(out_pinned ? static_cast<void *>(out + sl.r0) : sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double),
+                                       hipMemcpyDeviceToHost, g_ctx.d2h));
+            HIP_OR_FAIL(hipEventRecord(sl.ev_results, g_ctx.d2h));
+        }
     };
-    auto wait = [&](Slot &sl) {
+    // the slice's results have arrived (in the output column, or in the slot's pinned buffer): retire the call; copy if needed
+    auto finish = [&](Slot &sl) {
         tm.start();
-        if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+        if (sl.direct) {
+            if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message());
+        } else {
+            HIP_OR_FAIL(hipEventSynchronize(sl.ev_results));
+            // (the oldest call in flight is this slice's: slices are launched and finished in order)
+            if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+        }
         tm.stop(tm.t_wait);
+        const bool via_slot = sl.direct || !out_pinned;
         if (strsim_ctx_last_long_rows(ctx) != 0 && !sl.direct) { // rows finished by that pass: fetch the column again
             tm.start();
-            HIP_OR_FAIL(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_OR_FAIL(hipMemcpyAsync(via_slot ? sl.h_out.p : static_cast<void *>(out + sl.r0), sl.d_out.p, sl.rows * sizeof(double),
+                                       hipMemcpyDeviceToHost, stream));
             HIP_OR_FAIL(hipStreamSynchronize(stream));
             tm.stop(tm.t_d2h);
         }
-    };
-    auto copy_out = [&](Slot &sl) {
+        if (!via_slot) return;
         tm.start();
         const double *src = static_cast<const double *>(sl.h_out.p);
         const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
@@ -642,25 +824,38 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         tm.stop(tm.t_copy);
     };
 
-    // two slots: while the GPU works on slot `cur` (H2D, kernels, D2H) the host packs the next slice into the other
-    // slot, and it copies a finished slice out only after the next one has been launched
+    // Three slots: two slices in flight on the GPU (H2D + kernels of slice k+1 on the compute stream beside the D2H of slice
+    // k on the copy stream) while the host packs slice k+2.  PCIe carries 41 B in and 8 B out per pair in the two directions at once, the host
+    // touches every byte once (pack) -- per 2 M-row slice 1.45 ms of link against 1.3 ms of packing.  Slices ramp up from
+    // RAMP_ROWS and down again at the end, so that neither the first pack nor the last slice's trip is exposed at full size.
+    // (cutting a 1 M-row call into four equal slices was tried in round 1: the four small packs cost 1.3 ms instead of
+    // 0.6 ms and the call got slower -- hence the floor)
+    static const uint64_t RAMP_ROWS = env_rows("POLARS_STRSIM_RAMP_ROWS", 512u << 10);   // first slice (tuning knobs)
+    static const uint64_t FULL_ROWS = env_rows("POLARS_STRSIM_SLICE_ROWS", SLICE_ROWS);   // steady-state slice
+    static const uint64_t GROW_PCT = env_rows("POLARS_STRSIM_RAMP_GROW_PCT", 150);         // slice k+1 = slice k x this / 100
+    uint64_t prev_rows = 0;
+    auto next_rows = [&](uint64_t r0) -> uint64_t {
+        const uint64_t left = hi - r0;
+        if (direct_call || hi - lo <= (1u << 20)) return left;      // small calls: one slice
+        uint64_t want = prev_rows == 0 ? RAMP_ROWS : std::min<uint64_t>(FULL_ROWS, prev_rows * GROW_PCT / 100);
+        want = std::min<uint64_t>(want, SLICE_ROWS);
+        if (left < 2 * want) want = std::max<uint64_t>(RAMP_ROWS, ((left / 2 + 65535) >> 16) << 16); // taper
+        if (left <= want + RAMP_ROWS / 2) want = left;              // no crumbs
+        prev_rows = want;
+        return want;
+    };
     uint64_t r0 = lo;
-    int cur = 0;
-    // (cutting a 1 M-row call into four slices so that it pipelines too was tried: the four small packs cost
-    // 1.3 ms instead of 0.6 ms and the call got slower)
-    const uint64_t slice_rows = SLICE_ROWS;
-    tm.start(); r0 += pack(g_ctx.slot[cur], r0, slice_rows); tm.stop(tm.t_pack);
-    tm.start(); launch(g_ctx.slot[cur]); tm.stop(tm.t_launch);
+    unsigned k = 0;
+    tm.start(); r0 += pack(g_ctx.slot[0], r0, next_rows(r0)); tm.stop(tm.t_pack);
+    tm.start(); launch(g_ctx.slot[0]); tm.stop(tm.t_launch);
     while (r0 < hi) {
-        const int nxt = cur ^ 1;
-        tm.start(); r0 += pack(g_ctx.slot[nxt], r0, slice_rows); tm.stop(tm.t_pack); // overlaps the GPU work of slot `cur`
-        wait(g_ctx.slot[cur]);
-        tm.start(); launch(g_ctx.slot[nxt]); tm.stop(tm.t_launch);
-        copy_out(g_ctx.slot[cur]); // overlaps the GPU work of slot `nxt`
-        cur = nxt;
+        Slot &nxt = g_ctx.slot[(k + 1) % 3];
+        tm.start(); r0 += pack(nxt, r0, next_rows(r0)); tm.stop(tm.t_pack); // overlaps the GPU work of slices k-1, k
+        tm.start(); launch(nxt); tm.stop(tm.t_launch);
+        finish(g_ctx.slot[k % 3]);
+        ++k;
     }
-    wait(g_ctx.slot[cur]);
-    copy_out(g_ctx.slot[cur]);
+    finish(g_ctx.slot[k % 3]);
 }
 
 void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)
@@ -678,13 +873,15 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     const bool lit[2] = {a.rows == 1 && b.rows != 1, b.rows == 1};
     const uint64_t n = lit[0] ? b.rows : a.rows;
 
-    double *out = static_cast<double *>(alloc64(n * sizeof(double)));
+    double *out = static_cast<double *>(pinned_pool().acquire(n * sizeof(double))); // large columns (see PinnedPool)
+    const bool out_pinned = out != nullptr;
+    if (!out) out = static_cast<double *>(alloc64(n * sizeof(double)));
     uint8_t *validity = nullptr;
     int64_t null_count = 0;
     struct Cleanup {
-        double *&o; uint8_t *&v; bool armed = true;
-        ~Cleanup() { if (armed) { free(o); free(v); } }
-    } cleanup{out, validity};
+        double *&o; bool pinned; uint8_t *&v; bool armed = true;
+        ~Cleanup() { if (armed) { if (pinned) pinned_pool().release(o); else free(o); free(v); } }
+    } cleanup{out, out_pinned, validity};
 
     // a NULL literal: the reference unwrap()s and panics (strsim.rs:62,65,87,90); here every row is null
     const bool all_null = (lit[0] && !row_valid(a, 0)) || (lit[1] && !row_valid(b, 0));
@@ -698,13 +895,13 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         const uint64_t D = std::max<uint64_t>(1, std::min<uint64_t>(devs.size(), n / min_rows_per_device()));
         const unsigned T = std::max(1u, pack_threads(engine_parallel, n) / (unsigned)D);
         if (D == 1) {
-            run_shard(measure, col, lit, 0, n, out, T, direct_call, devs[0], tm);
+            run_shard(measure, col, lit, 0, n, out, out_pinned, T, direct_call, devs[0], tm);
         } else {
             std::vector<uint64_t> parts(2 * D);
             strsim_split_offsets(n, D, parts.data());
             std::vector<PhaseTimer> tms(D);
             g_devpool.run((unsigned)D, [&](unsigned d) {
-                run_shard(measure, col, lit, parts[2 * d], parts[2 * d] + parts[2 * d + 1], out, T, false, devs[d], tms[d]);
+                run_shard(measure, col, lit, parts[2 * d], parts[2 * d] + parts[2 * d + 1], out, out_pinned, T, false, devs[d], tms[d]);
             });
             for (const PhaseTimer &t : tms) { // (phase times of the shards ran concurrently: the longest of each is what the call saw)
                 tm.t_pack = std::max(tm.t_pack, t.t_pack); tm.t_wait = std::max(tm.t_wait, t.t_wait);
@@ -736,7 +933,7 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     }
 
     // one "g" chunk
-    ArrayPriv *ap = new ArrayPriv{out, validity, {validity, out}};
+    ArrayPriv *ap = new ArrayPriv{out, validity, {validity, out}, out_pinned};
     ArrowArray *arr = static_cast<ArrowArray *>(calloc(1, sizeof(ArrowArray)));
     arr->length = (int64_t)n;
     arr->null_count = null_count;

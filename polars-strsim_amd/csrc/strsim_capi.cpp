@@ -144,7 +144,32 @@ static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
     return STRSIM_OK;
 }
 
-// Retire every pending slot (the stream must already be synchronised).
+// Retire one pending slot whose kernels have completed: timing, counters, the long-string pass.  A slot is retired whatever
+// fails on the way (a slot left pending would be re-run by a later synchronize with buffers its caller may have freed).
+static int ctx_retire_slot(strsim_ctx *c, int s)
+{
+    int rc = STRSIM_OK;
+    c->slot_pending[s] = false;
+    if (c->slot_timed[s]) {
+        c->slot_timed[s] = false;
+        float a = 0, b = 0;
+        hipError_t e = hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
+        if (e == hipSuccess) {
+            c->lane_ms += a; c->wave_ms += b;
+            c->lane_launches++; c->wave_launches++;
+        } else {
+            rc = hip_fail(e, "hipEventElapsedTime");
+        }
+    }
+    const DevStatus &st = c->status_host[s];
+    c->last_wave_rows = st.wave_rows;
+    c->last_long_rows += st.huge_rows;
+    if (st.huge_rows != 0 && rc == STRSIM_OK) rc = ctx_run_huge(c, s, st);
+    return rc;
+}
+
+// Retire every pending slot (the stream must already be synchronised); the first error is what the caller gets.
 static int ctx_drain(strsim_ctx *c)
 {
     int rc = STRSIM_OK;
@@ -152,25 +177,8 @@ static int ctx_drain(strsim_ctx *c)
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
-        c->slot_pending[s] = false;
-        if (c->slot_timed[s]) {
-            // every slot is retired whatever fails on the way (a slot left pending would be re-run by a later synchronize
-            // with buffers its caller may have freed); the first error is what the caller gets
-            c->slot_timed[s] = false;
-            float a = 0, b = 0;
-            hipError_t e = hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]);
-            if (e == hipSuccess) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
-            if (e == hipSuccess) {
-                c->lane_ms += a; c->wave_ms += b;
-                c->lane_launches++; c->wave_launches++;
-            } else if (rc == STRSIM_OK) {
-                rc = hip_fail(e, "hipEventElapsedTime");
-            }
-        }
-        const DevStatus &st = c->status_host[s];
-        c->last_wave_rows = st.wave_rows;
-        c->last_long_rows += st.huge_rows;
-        if (st.huge_rows != 0 && rc == STRSIM_OK) rc = ctx_run_huge(c, s, st);
+        if (rc == STRSIM_OK) rc = ctx_retire_slot(c, s);
+        else c->slot_pending[s] = c->slot_timed[s] = false;
     }
     return rc;
 }
@@ -450,6 +458,19 @@ int strsim_ctx_synchronize(strsim_ctx_t *c)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ctx_drain(c);
+}
+
+int strsim_ctx_retire_oldest(strsim_ctx_t *c)
+{
+    if (!c) { set_error("strsim_ctx_retire_oldest: ctx is NULL"); return STRSIM_ERR_ARG; }
+    int rc = ctx_set_device(c);
+    if (rc) return rc;
+    c->last_long_rows = 0;
+    for (int k = 0; k < strsim_ctx::RING; ++k) {
+        const int s = (c->head + k) % strsim_ctx::RING; // oldest first
+        if (c->slot_pending[s]) return ctx_retire_slot(c, s);
+    }
+    return STRSIM_OK; // nothing pending (e.g. a small call that completed inside strsim_pairs_device_small)
 }
 
 int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const uint8_t *a_val, uint64_t a_rows,
