@@ -460,6 +460,99 @@ STRSIM_HD double epilogue_sorensen_dice(uint64_t isect, uint64_t la, uint64_t lb
     return 2.0 * (double)isect / (double)(la + lb);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The cores in ONE column loop over the text a (pattern = b, right-aligned planes): each column's match mask is built once
+// and feeds the Levenshtein recurrence (lev_myers32_snap's arrangement), Jaro's first pass (strsim.rs:200-230) and the
+// multiset intersection; Jaro's second pass (the zip of the flagged characters, :231-237) runs behind it and is the only
+// other place a match mask is built -- two per column instead of four when all three are wanted (BASELINE config 4), and
+// the single-measure kernels use the same loop with one core switched on.  What differs from jaro_match32 /
+// multiset_isect32 above, all of it to spend fewer and cheaper instructions (bench_support/micro/op_cost.hip):
+//   * no `live` mask: in the column groups below tmin every lane's text is still running, from tmin on a column runs under
+//     `column < la` (the exec mask), so a lane whose text has ended simply stops updating ALL of its state;
+//   * the low edge of Jaro's window is a variable shift of all-ones by max(i - bound, 0) (a saturating subtract and one
+//     shift) instead of a mask that is shifted along under a compare;
+//   * "a_i found a partner" is `cand != 0`, and the lowest candidate goes into the flags with one three-input op.
+// la, lb >= 1; tmin <= la <= tmax, both lane-uniform.  Outputs: dist (edit distance), m / t (Jaro matches, unequal zipped
+// pairs NOT halved), isect (sum of min counts); only those of the cores switched on are written.
+// ---------------------------------------------------------------------------------------------
+template <int NP, bool DO_LEV, bool DO_JARO, bool DO_ISECT>
+STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin, uint32_t tmax, uint32_t lb,
+                            const uint32_t (&P)[NP], uint32_t &dist, uint32_t &m_out, uint32_t &t_out, uint32_t &isect)
+{
+    const uint32_t lbmask = low_ones(lb);
+    // Levenshtein
+    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
+    // Jaro, first pass
+    const uint32_t mx = la > lb ? la : lb;
+    const uint32_t half = mx >> 1;
+    const uint32_t bound = (half ? half : 1u) - 1u; // mx/2 - 1 (:200); mx == 1 only for the 1x1 case, window {i}
+    uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb); // ones at [0, min(i+bound, lb-1)]
+    uint32_t fb = 0u, fa = 0u;
+    // multiset intersection
+    uint32_t used = 0u;
+#pragma unroll
+    for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+        if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
+        auto column = [&](int i) {
+            const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
+            if (DO_LEV) {
+                const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
+                const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
+                const uint32_t nX = twice(nHP);                                 // ~((HP << 1) | 1)
+                const uint32_t HN2 = twice(D0 & Pv);                            // HN << 1
+                Pv = bitop3<0xF2>(HN2, D0, nX);                                 // (HN << 1) | ~(D0 | X)
+                Mv = bitop3<0x50>(D0, D0, nX);                                  // D0 & X
+            }
+            if (DO_JARO) {
+                // candidates: equal, inside [max(i - bound, 0), min(i + bound, lb - 1)], not flagged yet
+                const uint32_t below = (uint32_t)i > bound ? (uint32_t)i - bound : 0u;   // (a saturating subtract)
+                const uint32_t notlow = 0xFFFFFFFFu << (below & 31u);                     // below <= 31
+                const uint32_t cand = bitop3<0x80>(Eq, himask, notlow) & ~fb;
+                fb = bitop3<0xF8>(fb, cand, 0u - cand);                                   // fb | lowest candidate
+                fa |= cand ? (1u << i) : 0u;
+                himask = ((himask << 1) | 1u) & lbmask;
+            }
+            if (DO_ISECT) {
+                const uint32_t cand = bitop3<0x08>(used, Eq, lbmask);                     // ~used & Eq & lbmask
+                used = bitop3<0xF8>(used, cand, 0u - cand);
+            }
+        };
+        if ((uint32_t)(COLS_PER_TEST * (g + 1)) >= tmin) {                 // (uniform) some lane's text may end in this group
+#pragma unroll
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj)
+                if ((uint32_t)(COLS_PER_TEST * g + jj) < la) column(COLS_PER_TEST * g + jj);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj) column(COLS_PER_TEST * g + jj);
+        }
+    }
+    if (DO_LEV) {
+        const uint32_t rows = lbmask;
+        dist = la + popc32(Pv & rows) - popc32(Mv & rows);
+    }
+    if (DO_ISECT) isect = popc32(used);
+    if (DO_JARO) {
+        // second pass: the k-th flagged character of a against the k-th flagged character of b (ascending positions); they
+        // are equal iff bit j_k of Eq(a_{i_k}) is set.  Columns at or beyond la have no flag, so no predicate is needed.
+        uint32_t t = 0u, rest = fb;
+#pragma unroll
+        for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
+            if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
+#pragma unroll
+            for (int ii = 0; ii < COLS_PER_TEST; ++ii) {
+                const int i = COLS_PER_TEST * g + ii;
+                const uint32_t on = bit_fill(fa, i);               // a_i was matched
+                const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
+                rest ^= jbit;
+                const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
+                t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+            }
+        }
+        m_out = popc32(fb);
+        t_out = t;
+    }
+}
+
 // The Jaro epilogue with its three integer quotients read from a table: q[a * QTAB_N + b] = (double)a / (double)b for
 // 0 <= a, b <= 64 (b = 0: unused), computed once with the same IEEE division -- an f64 division is ~40 VALU-equivalents
 // on CDNA.  Valid for strings of at most 32 characters.  (Measured on cfg2: Jaro +1.4 %; the single division of

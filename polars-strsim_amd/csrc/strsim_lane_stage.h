@@ -181,10 +181,8 @@ __device__ __forceinline__ unsigned long long stage_all_ints(const uint32_t (&wa
     build_planes<NP>(wb, P);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
-    uint32_t m, t;
-    jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
-    const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
-    const uint32_t dist = lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    uint32_t dist, m, t, isect; // one column loop, one match mask per column for the three cores (lane_cores32)
+    lane_cores32<NP, true, true, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
     const uint32_t pre = common_prefix4(wa[0], la1, wb[0], lb1);
     const uint32_t lo = dist | (m << 6) | (t << 12) | (isect << 18) | (pre << 24) | (la << 27); // la: 5 of its 6 bits fit here
     return (unsigned long long)lo | ((unsigned long long)(la >> 5) << 32) | ((unsigned long long)lb << 33);
@@ -215,19 +213,20 @@ __device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, doubl
 // One of the other four measures as 32 bits of integers: Jaro / Jaro-Winkler: m | t << 6 | la << 12 | lb << 18 | common
 // prefix << 24; Jaccard / Dice: I | la << 6 | lb << 12 (all-ones is never produced).  text = a, pattern = b.
 template <int MEASURE, int NP>
-__device__ __forceinline__ uint32_t stage_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb, uint32_t tmax)
+__device__ __forceinline__ uint32_t stage_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
+                                               uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
+    uint32_t dist, m, t, isect;
     if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
-        uint32_t m, t;
-        jaro_match32<NP>(wa, la1, tmax, lb1, P, m, t);
+        lane_cores32<NP, false, true, false>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
         const uint32_t pre = MEASURE == JARO_WINKLER ? common_prefix4(wa[0], la1, wb[0], lb1) : 0u;
         return m | (t << 6) | (la << 12) | (lb << 18) | (pre << 24);
     }
-    const uint32_t isect = multiset_isect32<NP>(wa, la1, tmax, lb1, P);
+    lane_cores32<NP, false, false, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
     return isect | (la << 6) | (lb << 12);
 }
 
@@ -291,8 +290,8 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
     } else {
         // the measure's integers, 32 bits per row; its f64 epilogue runs in the store phase (stage_epilogue)
         uint32_t pk;
-        if (wide) pk = stage_ints<MEASURE, 7>(wt, la, wp, lb, tmax);
-        else pk = stage_ints<MEASURE, 5>(wt, la, wp, lb, tmax);
+        if (wide) pk = stage_ints<MEASURE, 7>(wt, la, wp, lb, tmin, tmax);
+        else pk = stage_ints<MEASURE, 5>(wt, la, wp, lb, tmin, tmax);
         if (fast) s_word[idx] = pk;
     }
 }

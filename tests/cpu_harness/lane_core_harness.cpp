@@ -69,6 +69,39 @@ extern "C" uint32_t harness_lev_snap(const uint8_t *a, uint32_t la, const uint8_
     return lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
 }
 
+// the one-loop cores (lane_cores32) with all three cores on, and each of them on its own: out[0..3] = dist, m, t, isect of
+// the fused run; returns 0 when the single-core runs agree with it, else a code
+extern "C" int harness_cores32(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, uint32_t tmin, uint32_t tmax,
+                               int np, int fill, uint32_t *out)
+{
+    uint32_t wa[8], wb[8];
+    std::memset(wa, fill, sizeof wa);
+    std::memset(wb, fill, sizeof wb);
+    std::memcpy(wa, a, la);
+    std::memcpy(wb, b, lb);
+    uint32_t d = 0, m = 0, t = 0, is = 0, d1 = 0, m1 = 0, t1 = 0, is1 = 0, x = 0;
+    if (np == 5) {
+        uint32_t P[5];
+        build_planes<5>(wb, P);
+        lane_cores32<5, true, true, true>(wa, la, tmin, tmax, lb, P, d, m, t, is);
+        lane_cores32<5, true, false, false>(wa, la, tmin, tmax, lb, P, d1, x, x, x);
+        lane_cores32<5, false, true, false>(wa, la, tmin, tmax, lb, P, x, m1, t1, x);
+        lane_cores32<5, false, false, true>(wa, la, tmin, tmax, lb, P, x, x, x, is1);
+    } else {
+        uint32_t P[7];
+        build_planes<7>(wb, P);
+        lane_cores32<7, true, true, true>(wa, la, tmin, tmax, lb, P, d, m, t, is);
+        lane_cores32<7, true, false, false>(wa, la, tmin, tmax, lb, P, d1, x, x, x);
+        lane_cores32<7, false, true, false>(wa, la, tmin, tmax, lb, P, x, m1, t1, x);
+        lane_cores32<7, false, false, true>(wa, la, tmin, tmax, lb, P, x, x, x, is1);
+    }
+    out[0] = d; out[1] = m; out[2] = t; out[3] = is;
+    if (d1 != d) return 1;
+    if (m1 != m || t1 != t) return 2;
+    if (is1 != is) return 3;
+    return 0;
+}
+
 // plane build vs the definition, for any 32 bytes
 extern "C" int harness_check_planes(const uint8_t *bytes32)
 {

@@ -36,6 +36,9 @@ def harness():
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
     L.harness_lev_snap.restype = C.c_uint32
     L.harness_lev_snap.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    L.harness_cores32.restype = C.c_int
+    L.harness_cores32.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                  C.POINTER(C.c_uint32)]
     L.harness_check_planes.restype = C.c_int
     L.harness_check_planes.argtypes = [C.c_char_p]
     return L
@@ -231,3 +234,66 @@ def test_levenshtein_snapshot_core(harness, np_, alphabet):
         tmax = min(32, (rng.randint(len(a), 32) + 1) & ~1)
         got = harness.harness_lev_snap(a.encode(), len(a), b.encode(), len(b), tmin, max(tmax, len(a) + (len(a) & 1)), np_, fill)
         assert got == _edit_distance(a, b), (a, b, tmin, tmax)
+
+
+def _jaro_ints(a, b):
+    """(m, t) of Jaro::compute, strsim.rs:200-237: t = unequal pairs in the zip of the flagged characters, NOT halved."""
+    la, lb = len(a), len(b)
+    bound = max(la, lb) // 2
+    bound = bound - 1 if bound > 0 else 0
+    fa, fb = [False] * la, [False] * lb
+    m = 0
+    for i in range(la):
+        lo = max(0, i - bound)
+        hi = min(lb - 1, i + bound)
+        for j in range(lo, hi + 1):
+            if a[i] == b[j] and not fb[j]:
+                fa[i] = fb[j] = True
+                m += 1
+                break
+    xa = [a[i] for i in range(la) if fa[i]]
+    xb = [b[j] for j in range(lb) if fb[j]]
+    return m, sum(1 for x, y in zip(xa, xb) if x != y)
+
+
+def _isect(a, b):
+    from collections import Counter
+    ca, cb = Counter(a), Counter(b)
+    return sum(min(ca[c], cb[c]) for c in ca)
+
+
+@pytest.mark.parametrize("np_,alphabet", [(5, "abcdefghijklmnopqrstuvwxyz"), (5, "ab"), (5, "abc"), (7, "aZ09 ~!bcXY")])
+def test_one_loop_cores(harness, np_, alphabet):
+    """lane_cores32 (one column loop, one match mask per column for the three cores -- what the staged kernels run for Jaro,
+    Jaro-Winkler, Jaccard, Dice and the five-output pass) = edit distance, Jaro's (m, t) and the multiset intersection by
+    their definitions, and the single-core instantiations agree with the fused one; every way a wave can run it."""
+    rng = random.Random(70 + np_ + len(alphabet))
+    fill = ord("q") if np_ == 5 else ord("#")
+    out = (C.c_uint32 * 4)()
+    for _ in range(3000):
+        la, lb = rng.randint(1, 32), rng.randint(1, 32)
+        a = "".join(rng.choice(alphabet) for _ in range(la))
+        if rng.random() < 0.5:
+            b = list(a)
+            for _e in range(rng.randint(0, 3)):
+                k = rng.randrange(len(b) + 1)
+                r = rng.random()
+                if r < 0.25 and b:
+                    del b[min(k, len(b) - 1)]
+                elif r < 0.5:
+                    b.insert(k, rng.choice(alphabet))
+                elif r < 0.75 and len(b) > 1:
+                    k = min(k, len(b) - 2)
+                    b[k], b[k + 1] = b[k + 1], b[k]
+                elif b:
+                    b[min(k, len(b) - 1)] = rng.choice(alphabet)
+            b = "".join(b)[:32] or rng.choice(alphabet)
+        else:
+            b = "".join(rng.choice(alphabet) for _ in range(lb))
+        tmin = rng.randint(1, len(a))
+        tmax = max(min(32, (rng.randint(len(a), 32) + 1) & ~1), len(a) + (len(a) & 1))
+        rc = harness.harness_cores32(a.encode(), len(a), b.encode(), len(b), tmin, tmax, np_, fill, out)
+        assert rc == 0, (rc, a, b, tmin, tmax)
+        assert out[0] == _edit_distance(a, b), (a, b, tmin, tmax)
+        assert (out[1], out[2]) == _jaro_ints(a, b), (a, b, tmin, tmax, out[1], out[2])
+        assert out[3] == _isect(a, b), (a, b, tmin, tmax)
