@@ -61,6 +61,81 @@ STRSIM_HD uint32_t any_wide(const uint32_t (&x)[W])
     return o;
 }
 
+// ---- W-word shifts and decrements as carry chains --------------------------------------------------
+// On gfx950 an add-with-carry costs one full-rate issue slot and a 32-bit left shift two (bench_support/micro/op_cost.hip),
+// so "shift the W-word mask left by one and bring a bit in" is W v_addc_co_u32 with the incoming bit as the first carry, and
+// "x - 1" (for the lowest set bit, x & ~(x - 1)) is one v_subrev_co_u32 + W - 1 v_subbrev_co_u32.  A chain lives in ONE asm
+// statement (VCC must survive from one instruction to the next); the host versions are the plain arithmetic.
+#if defined(__HIP_DEVICE_COMPILE__)
+// x = (x << 1) | 1
+STRSIM_HD void shl1_one(uint32_t (&x)[1]) { x[0] = x[0] + x[0] + 1u; }
+STRSIM_HD void shl1_one(uint32_t (&x)[2])
+{
+    asm("s_mov_b64 vcc, -1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(x[0]), "+v"(x[1]) : : "vcc");
+}
+STRSIM_HD void shl1_one(uint32_t (&x)[4])
+{
+    asm("s_mov_b64 vcc, -1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : : "vcc");
+}
+// x = (x << 1) | (a >= b)
+STRSIM_HD void shl1_ge(uint32_t (&x)[1], uint32_t a, uint32_t b) { x[0] = x[0] + x[0] + (a >= b ? 1u : 0u); }
+STRSIM_HD void shl1_ge(uint32_t (&x)[2], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(x[0]), "+v"(x[1]) : "s"(a), "v"(b) : "vcc"); // (a: the column index, wave-uniform)
+}
+STRSIM_HD void shl1_ge(uint32_t (&x)[4], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_ge_u32_e32 vcc, %4, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "s"(a), "v"(b) : "vcc");
+}
+// (x << 1) | (v != 0), one word
+STRSIM_HD uint32_t shl1_nz(uint32_t x, uint32_t v)
+{
+    asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(v) : "vcc");
+    return x;
+}
+// x + (v != 0)
+STRSIM_HD uint32_t add_nz(uint32_t x, uint32_t v)
+{
+    asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(x) : "v"(v) : "vcc");
+    return x;
+}
+// d = x - 1 over W words
+STRSIM_HD void minus1_wide(const uint32_t (&x)[1], uint32_t (&d)[1]) { d[0] = x[0] - 1u; }
+STRSIM_HD void minus1_wide(const uint32_t (&x)[2], uint32_t (&d)[2])
+{
+    asm("v_subrev_co_u32_e32 %0, vcc, 1, %2\n\tv_subbrev_co_u32_e32 %1, vcc, 0, %3, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]) : "v"(x[0]), "v"(x[1]) : "vcc");
+}
+STRSIM_HD void minus1_wide(const uint32_t (&x)[4], uint32_t (&d)[4])
+{
+    asm("v_subrev_co_u32_e32 %0, vcc, 1, %4\n\tv_subbrev_co_u32_e32 %1, vcc, 0, %5, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, 0, %6, vcc\n\tv_subbrev_co_u32_e32 %3, vcc, 0, %7, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]) : "vcc");
+}
+#else
+template <int W> STRSIM_HD void shl1_one(uint32_t (&x)[W]) { shl1_in<W>(x, 1u); }
+template <int W> STRSIM_HD void shl1_ge(uint32_t (&x)[W], uint32_t a, uint32_t b) { shl1_in<W>(x, a >= b ? 1u : 0u); }
+STRSIM_HD uint32_t shl1_nz(uint32_t x, uint32_t v) { return (x << 1) | (v ? 1u : 0u); }
+STRSIM_HD uint32_t add_nz(uint32_t x, uint32_t v) { return x + (v ? 1u : 0u); }
+template <int W> STRSIM_HD void minus1_wide(const uint32_t (&x)[W], uint32_t (&d)[W])
+{
+    uint32_t borrow = 1u;
+    for (int w = 0; w < W; ++w) {
+        d[w] = x[w] - borrow;
+        borrow = (x[w] < borrow) ? 1u : 0u;
+    }
+}
+#endif
+
+// 0xFFFFFFFF where the signed x is negative, else 0 (v_ashrrev_i32: full rate)
+STRSIM_HD uint32_t sign_fill(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
+
 // Planes of a 32*W-byte window (dwords wp[0 .. 8W)): P[k][w] bit i = bit k of byte 32w + i.
 template <int NP, int W>
 STRSIM_HD void build_planes_wide(const uint32_t (&wp)[8 * W], uint32_t (&P)[NP][W])
@@ -151,38 +226,45 @@ template <int NP, int W, class Txt, class FaStore, class FaLoad>
 STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W],
                          const FaStore &fa_store, const FaLoad &fa_load, uint32_t &m_out, uint32_t &t_out)
 {
+    // Instruction diet: the two window masks move along as carry chains (himask is not clamped to lb -- the
+    // match masks already are), "this column is past the end of a" is the sign of a running counter, the lowest candidate is
+    // folded into the flags with one three-input op per word, and the "a_i found a partner" bits are shifted in from the
+    // right by an add-with-carry (column c of a 32-column group ends at bit 31 - c; the second pass reads them from the top
+    // with an arithmetic shift).
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u;
     uint32_t lbmask[W], himask[W], lomask[W], fb[W];
     low_ones_wide<W>(lb, lbmask);
-    low_ones_wide<W>((bound + 1u) < lb ? (bound + 1u) : lb, himask);
+    low_ones_wide<W>(bound + 1u, himask); // ones at [0, i + bound]
 #pragma unroll
     for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
     uint32_t fa_acc = 0u;
+    uint32_t left = la - 1u; // la - 1 - i: negative from column la on
     for (uint32_t g = 0; g < ng4; ++g) {
         const uint32_t c4 = txt(g);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const uint32_t i = 4u * g + (uint32_t)ii;
-            const uint32_t live = i < la ? 0xFFFFFFFFu : 0u;
-            uint32_t Eq[W], cand[W], bit[W];
+            const uint32_t dead = sign_fill(left); // all ones once i >= la
+            left -= 1u;
+            uint32_t Eq[W], cand[W], d[W];
             eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
 #pragma unroll
-            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x20>(Eq[w] & himask[w], lomask[w] | fb[w], live); // a & ~b & c
-            lowest_bit_wide<W>(cand, bit);
+            for (int w = 0; w < W; ++w) {
+                const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
+                cand[w] = bitop3<0x10>(inwin, fb[w], dead);                       // inwin & ~fb & ~dead
+            }
+            minus1_wide(cand, d);
 #pragma unroll
-            for (int w = 0; w < W; ++w) fb[w] |= bit[w];
-            const uint32_t matched = any_wide<W>(bit) ? 1u : 0u;
-            fa_acc = (fa_acc >> 1) | (matched << 31); // column i ends at bit (i & 31) once its 32-group is complete
-            shl1_in<W>(himask, 1u);
-#pragma unroll
-            for (int w = 0; w < W; ++w) himask[w] &= lbmask[w];
-            shl1_in<W>(lomask, i >= bound ? 1u : 0u);
+            for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
+            fa_acc = shl1_nz(fa_acc, any_wide<W>(cand));
+            shl1_one(himask);
+            shl1_ge(lomask, i, bound);
         }
         if ((g & 7u) == 7u) { fa_store(g >> 3, fa_acc); fa_acc = 0u; }
     }
-    if ((ng4 & 7u) != 0u) fa_store(ng4 >> 3, fa_acc >> (32u - 4u * (ng4 & 7u))); // partial last group: right-align
+    if ((ng4 & 7u) != 0u) fa_store(ng4 >> 3, fa_acc << (32u - 4u * (ng4 & 7u))); // partial last group: top-align
 
     uint32_t rest[W];
 #pragma unroll
@@ -193,18 +275,19 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
         const uint32_t c4 = txt(g);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t on = bit_fill(fa_cur, 0);
-            fa_cur >>= 1;
-            uint32_t Eq[W], jbit[W], miss[W];
+            const uint32_t on = sign_fill(fa_cur); // a_i was matched
+            fa_cur += fa_cur;
+            uint32_t Eq[W], d[W];
             eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
-            lowest_bit_wide<W>(rest, jbit);
+            minus1_wide(rest, d);
+            uint32_t miss = 0u;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                jbit[w] &= on;
-                rest[w] ^= jbit[w];
-                miss[w] = jbit[w] & ~Eq[w];
+                const uint32_t jbit = bitop3<0x20>(rest[w], d[w], on); // lowest remaining flag of b, if a_i is matched
+                rest[w] = bitop3<0xD0>(rest[w], d[w], on);             // rest & (d | ~on): that flag is used up
+                miss = bitop3<0xF4>(miss, jbit, Eq[w]);                // miss | (jbit & ~Eq)
             }
-            t += any_wide<W>(miss) ? 1u : 0u;
+            t = add_nz(t, miss);
         }
     }
     uint32_t m = 0u;
