@@ -351,9 +351,7 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     uint32_t vary = 0u;
     if (has) {
         load_window_any<8 * W>(valA, (int64_t)a0, totalA, ta);
-        // Levenshtein wants b left-aligned: take the window that ENDS at the end of b
-        const int64_t bstart = MEASURE == LEVENSHTEIN ? (int64_t)b0 + (int64_t)lb - 32 * W : (int64_t)b0;
-        load_window_any<8 * W>(valB, bstart, totalB, wp);
+        load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
         if (MEASURE == JARO_WINKLER) b0w = wp[0];
         uint32_t o = ta[0] | wp[0], n = ta[0] & wp[0];
 #pragma unroll
@@ -367,6 +365,7 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     for (int d = 0; d < 8 * W; ++d) txt_col[d * 64] = ta[d];
     const uint32_t lae = fast ? la : 1u, lbe = fast ? lb : 1u;
     const uint32_t ng4 = (wave_max_u8(fast ? la : 0u) + 3u) >> 2;
+    const uint32_t gfull = (255u - wave_max_u8(255u - (fast ? la : 255u))) >> 2; // text dwords before the shortest live text ends
     done = false;
     if (__ballot(fast) == 0ull) return;
     const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
@@ -376,8 +375,8 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const LdsFaLoad fld{fa_col};
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation, cf. k_lane_pairs)
     __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
-    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
-    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, ta[0], b0w, fst, fld);
     __builtin_amdgcn_s_setprio(1);
     done = fast;
 }

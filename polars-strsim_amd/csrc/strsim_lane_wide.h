@@ -133,6 +133,45 @@ template <int W> STRSIM_HD void minus1_wide(const uint32_t (&x)[W], uint32_t (&d
 }
 #endif
 
+// s = x + y over W words; x = x << 1 over W words
+#if defined(__HIP_DEVICE_COMPILE__)
+STRSIM_HD void add_wide(const uint32_t (&x)[1], const uint32_t (&y)[1], uint32_t (&s)[1]) { s[0] = x[0] + y[0]; }
+STRSIM_HD void add_wide(const uint32_t (&x)[2], const uint32_t (&y)[2], uint32_t (&s)[2])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %2, %4\n\tv_addc_co_u32_e32 %1, vcc, %3, %5, vcc"
+        : "=&v"(s[0]), "=&v"(s[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]) : "vcc");
+}
+STRSIM_HD void add_wide(const uint32_t (&x)[4], const uint32_t (&y)[4], uint32_t (&s)[4])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %4, %8\n\tv_addc_co_u32_e32 %1, vcc, %5, %9, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %6, %10, vcc\n\tv_addc_co_u32_e32 %3, vcc, %7, %11, vcc"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]) : "vcc");
+}
+STRSIM_HD void shl1_zero(uint32_t (&x)[1]) { x[0] = x[0] + x[0]; }
+STRSIM_HD void shl1_zero(uint32_t (&x)[2])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %0, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(x[0]), "+v"(x[1]) : : "vcc");
+}
+STRSIM_HD void shl1_zero(uint32_t (&x)[4])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %0, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : : "vcc");
+}
+#else
+template <int W> STRSIM_HD void add_wide(const uint32_t (&x)[W], const uint32_t (&y)[W], uint32_t (&s)[W])
+{
+    uint32_t carry = 0u;
+    for (int w = 0; w < W; ++w) {
+        const uint64_t t = (uint64_t)x[w] + y[w] + carry;
+        s[w] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+}
+template <int W> STRSIM_HD void shl1_zero(uint32_t (&x)[W]) { shl1_in<W>(x, 0u); }
+#endif
+
 // 0xFFFFFFFF where the signed x is negative, else 0 (v_ashrrev_i32: full rate)
 STRSIM_HD uint32_t sign_fill(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
 
@@ -168,53 +207,57 @@ STRSIM_HD void eq_wide(const uint32_t (&P)[NP][W], const uint32_t (&valid)[W], u
 }
 
 // ---------------------------------------------------------------------------------------------
-// Levenshtein, W-word Myers/Hyyro.  The pattern b is LEFT-aligned in the 32*W-bit vector: its planes
-// come from the window that ENDS at the end of b (the caller loads bytes [end - 32W, end)), so position j
-// of b is bit j + s, s = 32W - lb, and the score row is the top bit.  Bits below s are the fictitious
-// shared prefix (see strsim_lane_core.h).  The running score is updated only while the column index is
-// below the lane's own la (ng4 = number of text dwords the wave walks, uniform).  la, lb >= 1.
+// Levenshtein, W-word Myers/Hyyro in the arrangement of lev_myers32_snap (strsim_lane_core.h): the pattern b is RIGHT-aligned
+// (bit j = b[j], planes of the window that starts at b; rows at and above lb belong to whatever follows b and never
+// influence the rows below them), ~HP is carried, every shift and the W-word addition are carry chains, and a lane whose
+// text has ended keeps its (Pv, Mv): text dwords below gfull (lane-uniform: every lane's text is still running there) run
+// as they are, the ones from gfull on run each column under `column < la`.  The distance after exactly la columns is
+// la + popc(Pv) - popc(Mv) over the pattern's rows.  la, lb >= 1; ng4 = text dwords the wave walks (uniform).
 // ---------------------------------------------------------------------------------------------
 template <int NP, int W, class Txt>
-STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t ng4, const uint32_t (&P)[NP][W], uint32_t lb)
+STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const uint32_t (&P)[NP][W], uint32_t lb)
 {
-    const uint32_t s = 32u * W - lb;
-    uint32_t lowm[W], valid[W], Pv[W], Mv[W];
-    low_ones_wide<W>(s, lowm);
+    uint32_t all[W], Pv[W], Mv[W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) { valid[w] = ~lowm[w]; Pv[w] = valid[w]; Mv[w] = lowm[w]; }
-    uint32_t score = lb;
-    for (uint32_t g = 0; g < ng4; ++g) {
+    for (int w = 0; w < W; ++w) { all[w] = 0xFFFFFFFFu; Pv[w] = 0xFFFFFFFFu; Mv[w] = 0u; }
+    auto column = [&](uint32_t c4, int jj) {
+        uint32_t Eq[W], X[W], S[W], D0[W], nX[W], HN2[W];
+        eq_wide<NP, W>(P, all, c4, jj, Eq);
+#pragma unroll
+        for (int w = 0; w < W; ++w) X[w] = Eq[w] & Pv[w];
+        add_wide(X, Pv, S);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            D0[w] = bitop3<0xBE>(S[w], Pv[w], Eq[w]) | Mv[w]; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
+            nX[w] = bitop3<0x0E>(Mv[w], D0[w], Pv[w]);        // ~HP = ~Mv & (D0 | Pv)
+            HN2[w] = D0[w] & Pv[w];                            // HN
+        }
+        shl1_zero(nX);  // ~((HP << 1) | 1)
+        shl1_zero(HN2); // HN << 1
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            Pv[w] = bitop3<0xF2>(HN2[w], D0[w], nX[w]); // (HN << 1) | ~(D0 | X)
+            Mv[w] = bitop3<0x50>(D0[w], D0[w], nX[w]);  // D0 & X
+        }
+    };
+    uint32_t g = 0;
+    for (; g < gfull && g < ng4; ++g) {
         const uint32_t c4 = txt(g);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            uint32_t Eq[W];
-            eq_wide<NP, W>(P, valid, c4, jj, Eq);
-            // t = (Eq & Pv) + Pv  (W-word add)
-            uint32_t D0[W];
-            uint32_t carry = 0u;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t x = Eq[w] & Pv[w];
-                const uint32_t s1 = x + Pv[w];
-                const uint32_t c1 = s1 < x ? 1u : 0u;
-                const uint32_t s2 = s1 + carry;
-                const uint32_t c2 = s2 < s1 ? 1u : 0u;
-                carry = c1 | c2;
-                D0[w] = bitop3<0xBE>(s2, Pv[w], Eq[w] | Mv[w]);
-            }
-            uint32_t HP[W], HN[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) { HP[w] = bitop3<0xF1>(Mv[w], D0[w], Pv[w]); HN[w] = Pv[w] & D0[w]; }
-            const uint32_t col = 4u * g + (uint32_t)jj;
-            const uint32_t delta = (HP[W - 1] >> 31) - (HN[W - 1] >> 31);
-            score += col < la ? delta : 0u;
-            shl1_in<W>(HP, 1u); // X
-            shl1_in<W>(HN, 0u);
-#pragma unroll
-            for (int w = 0; w < W; ++w) { Pv[w] = bitop3<0xF1>(HN[w], D0[w], HP[w]); Mv[w] = D0[w] & HP[w]; }
-        }
+        for (int jj = 0; jj < 4; ++jj) column(c4, jj);
     }
-    return score;
+    for (; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (4u * g + (uint32_t)jj < la) column(c4, jj);
+    }
+    uint32_t rows[W];
+    low_ones_wide<W>(lb, rows);
+    uint32_t up = 0u, down = 0u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) { up += popc32(Pv[w] & rows[w]); down += popc32(Mv[w] & rows[w]); }
+    return la + up - down;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,18 +348,20 @@ STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_
     low_ones_wide<W>(lb, lbmask);
 #pragma unroll
     for (int w = 0; w < W; ++w) used[w] = 0u;
+    uint32_t left = la - 1u; // la - 1 - i: negative from column la on
     for (uint32_t g = 0; g < ng4; ++g) {
         const uint32_t c4 = txt(g);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t live = (4u * g + (uint32_t)ii) < la ? 0xFFFFFFFFu : 0u;
-            uint32_t Eq[W], cand[W], bit[W];
+            const uint32_t dead = sign_fill(left);
+            left -= 1u;
+            uint32_t Eq[W], cand[W], d[W];
             eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
 #pragma unroll
-            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x20>(Eq[w], used[w], live);
-            lowest_bit_wide<W>(cand, bit);
+            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x10>(Eq[w], used[w], dead); // Eq & ~used & ~dead
+            minus1_wide(cand, d);
 #pragma unroll
-            for (int w = 0; w < W; ++w) used[w] |= bit[w];
+            for (int w = 0; w < W; ++w) used[w] = bitop3<0xF4>(used[w], cand[w], d[w]); // used | lowest candidate
         }
     }
     uint32_t n = 0u;
@@ -327,17 +372,17 @@ STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_
 
 // ---------------------------------------------------------------------------------------------
 // One lane's result, strings of 1..32*W ASCII bytes each (the empty cases never reach the wide path).
-// wp = the pattern window: for Levenshtein the 32W bytes that END at the end of b, else the 32W bytes
-// that START at b.  a0w / b0w = first dwords of a and b (Jaro-Winkler prefix).
+// wp = the pattern window: the 32W bytes that START at b.  a0w / b0w = first dwords of a and b (Jaro-Winkler prefix).
+// gfull <= la / 4 for every lane of the wave (text dwords in which no lane's text ends), ng4 = text dwords to walk.
 // ---------------------------------------------------------------------------------------------
 template <int MEASURE, int NP, int W, class Txt, class FaStore, class FaLoad>
-STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t ng4, const uint32_t (&wp)[8 * W], uint32_t lb,
+STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const uint32_t (&wp)[8 * W], uint32_t lb,
                                   uint32_t a0w, uint32_t b0w, const FaStore &fa_store, const FaLoad &fa_load)
 {
     uint32_t P[NP][W];
     build_planes_wide<NP, W>(wp, P);
     if (MEASURE == LEVENSHTEIN) {
-        return epilogue_levenshtein(lev_wide<NP, W>(txt, la, ng4, P, lb), la, lb);
+        return epilogue_levenshtein(lev_wide<NP, W>(txt, la, gfull, ng4, P, lb), la, lb);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
         jaro_wide<NP, W>(txt, la, ng4, lb, P, fa_store, fa_load, m, t);

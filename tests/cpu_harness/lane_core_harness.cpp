@@ -133,7 +133,9 @@ static double run_wide_np(const uint32_t *ta, uint32_t la, const uint32_t (&wp)[
 {
     uint32_t fa[W + 1] = {0};
     const uint32_t ng4 = (la + 3u) / 4u;
-    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, ng4, wp, lb, ta[0], b0w, FaSt{fa}, FaLd{fa});
+    // (gfull: any value up to la / 4; the kernel passes the wave's minimum -- sweep it through a few)
+    const uint32_t gfull = (la / 4u) * ((la ^ lb) & 3u) / 3u;
+    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, ta[0], b0w, FaSt{fa}, FaLd{fa});
 }
 
 template <int M, int W>
@@ -146,10 +148,6 @@ static double run_wide(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t
     std::memset(buf, fill, sizeof buf);
     std::memcpy(buf, b, lb);
     std::memcpy(wbn, buf, sizeof buf);            // natural window (starts at b)
-    if (M == LEVENSHTEIN) {                       // window that ENDS at the end of b
-        std::memset(buf, fill, sizeof buf);
-        std::memcpy(buf + 32 * W - lb, b, lb);
-    }
     std::memcpy(wp, buf, sizeof buf);
     // varying bits over both windows
     uint32_t o = 0, n = 0xFFFFFFFFu;
