@@ -399,6 +399,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
     __shared__ uint32_t s_cnt[16];              // rows per key = width class (2) x column-count bucket (8)
+    __shared__ uint32_t s_next;                 // next round to hand out
     __shared__ uint16_t s_list[WIDE_ROWS];      // candidate rows (index within the span), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
     __shared__ uint32_t s_fa[WIDE_WAVES][WIDE_MAXW + 1][64];
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 16u) s_cnt[tid] = 0u;
+        if (tid == 16u) s_next = 0u;
         lds_barrier();
         const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
@@ -465,9 +467,15 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 }
             }
             lds_barrier();
-            // ---- rounds of 64 rows of similar width and length, dealt over the waves (longest first)
+            // ---- rounds of 64 rows of similar width and length, longest first; a wave takes the next one when it is done
+            //      (a four-word round costs four times a two-word one: dealing them out in turn leaves waves idle at the
+            //      barrier behind the span)
             const uint32_t nrounds = (total + 63u) >> 6;
-            for (uint32_t rr = wv; rr < nrounds; rr += WIDE_WAVES) {
+            for (;;) {
+                uint32_t rr = 0u;
+                if (lane == 0u) rr = atomicAdd(&s_next, 1u);
+                rr = uniform(rr);
+                if (rr >= nrounds) break;
                 const uint32_t r = nrounds - 1u - rr;
                 const uint32_t li = r * 64u + lane;
                 const bool has = li < total;
