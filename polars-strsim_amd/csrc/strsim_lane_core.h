@@ -102,6 +102,18 @@ STRSIM_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+// x + x as an add the compiler cannot turn back into a shift (v_lshlrev_b32 costs two issue slots on gfx950, v_add_u32 one)
+STRSIM_HD uint32_t twice(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x + x;
+#endif
+}
+
 // 8x8 bit-matrix transpose of the eight bytes {lo, hi}: afterwards byte k holds bit k of the eight
 // source bytes (bit i of byte k = bit k of source byte i).  Three block-swap rounds (1, 2, 4 bits).
 // (written with explicit three-input ops: (a ^ b) & c = 0x28, a ^ b ^ c = 0x96 -- hipcc does not form v_bitop3_b32 from
@@ -120,8 +132,57 @@ STRSIM_HD void transpose8x8(uint32_t &lo, uint32_t &hi)
 }
 
 // Planes 0..NP-1 of the 32 pattern bytes w[0..7] (NP in 1..8).
+// Two 4x4 byte transposes first (sixteen v_perm_b32): register e then holds bytes e, e + 8, e + 16, e + 24, i.e. its bit
+// 8y + k is bit k of byte 8y + e.  What remains is to exchange the register index e with the in-byte bit index k, for the
+// four byte lanes at once: three rounds of delta swaps BETWEEN registers (bit t of e against bit t of k), each half of a
+// swap one shift and one three-input select -- and the halves that would only feed planes NP .. 7 are never computed.
+// 58 instructions for five planes where the within-register transposes (build_planes_r1 below: three rounds on each pair of
+// dwords, then the byte transposes of the planes) take 91, and 191 instead of 293 cycles of SIMD time (gfx950 issue costs,
+// bench_support/micro/op_cost.hip).
 template <int NP>
 STRSIM_HD void build_planes(const uint32_t (&w)[8], uint32_t (&P)[NP])
+{
+    uint32_t r[8];
+    {
+        // r[e] byte y = w[2y + (e >> 2)] byte (e & 3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t t0 = perm_b32(w[2 + h], w[0 + h], 0x05010400u); // [w0.b0, w2.b0, w0.b1, w2.b1]
+            const uint32_t t1 = perm_b32(w[2 + h], w[0 + h], 0x07030602u); // [w0.b2, w2.b2, w0.b3, w2.b3]
+            const uint32_t t2 = perm_b32(w[6 + h], w[4 + h], 0x05010400u);
+            const uint32_t t3 = perm_b32(w[6 + h], w[4 + h], 0x07030602u);
+            r[4 * h + 0] = perm_b32(t2, t0, 0x05040100u);
+            r[4 * h + 1] = perm_b32(t2, t0, 0x07060302u);
+            r[4 * h + 2] = perm_b32(t3, t1, 0x05040100u);
+            r[4 * h + 3] = perm_b32(t3, t1, 0x07060302u);
+        }
+    }
+    // round t: registers e (bit t clear) and e | 2^t; M = the bit positions whose in-byte index has bit t clear
+    //   low'  = M ? low : high << 2^t        high' = M ? low >> 2^t : high          (bitop3 0xCA = a ? b : c)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const uint32_t a = r[e], b = r[e + 1];
+        r[e] = bitop3<0xCA>(0x55555555u, a, twice(b));
+        r[e + 1] = bitop3<0xCA>(0x55555555u, a >> 1, b);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (q & 1) | ((q & 2) << 1); // 0, 1, 4, 5
+        const uint32_t a = r[e], b = r[e + 2];
+        r[e] = bitop3<0xCA>(0x33333333u, a, b << 2);
+        r[e + 2] = bitop3<0xCA>(0x33333333u, a >> 2, b);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t a = r[e], b = r[e + 4];
+        if (e < NP) P[e < NP ? e : 0] = bitop3<0xCA>(0x0F0F0F0Fu, a, b << 4);
+        if (e + 4 < NP) P[e + 4 < NP ? e + 4 : 0] = bitop3<0xCA>(0x0F0F0F0Fu, a >> 4, b);
+    }
+}
+
+// The round-1 arrangement (kept for the CPU harness to check the two against each other).
+template <int NP>
+STRSIM_HD void build_planes_r1(const uint32_t (&w)[8], uint32_t (&P)[NP])
 {
     uint32_t lo[4], hi[4];
 #pragma unroll
@@ -246,18 +307,6 @@ STRSIM_HD uint32_t lev_myers32(const uint32_t (&wt)[8], uint32_t lt, uint32_t tm
 //   * ~HP is carried instead of HP: (HP << 1) | 1 = ~(~HP + ~HP), which folds into the two v_bitop3 that consume it.
 // lt, lp >= 1; tmin <= lt <= tmax, both lane-uniform.
 // ---------------------------------------------------------------------------------------------
-// x + x as an add the compiler cannot turn back into a shift (v_lshlrev_b32 costs two issue slots on gfx950, v_add_u32 one)
-STRSIM_HD uint32_t twice(uint32_t x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_add_u32_e32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return r;
-#else
-    return x + x;
-#endif
-}
-
 #ifndef STRSIM_LEV_FREEZE
 #define STRSIM_LEV_FREEZE 1
 #endif

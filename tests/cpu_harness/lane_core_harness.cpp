@@ -114,6 +114,9 @@ extern "C" int harness_check_planes(const uint8_t *bytes32)
         for (int i = 0; i < 32; ++i) ref |= (uint32_t)((bytes32[i] >> k) & 1u) << i;
         if (ref != P[k]) return k + 1;
     }
+    uint32_t R[8];
+    build_planes_r1<8>(w, R);
+    for (int k = 0; k < 8; ++k) if (R[k] != P[k]) return 300 + k;
     uint32_t P5[5];
     build_planes<5>(w, P5);
     for (int k = 0; k < 5; ++k) if (P5[k] != P[k]) return 100 + k;
