@@ -1811,13 +1811,16 @@ static void launch_lane_t(const LaunchArgs &a)
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
-    if (a.stage_grid > 0 && M == LEVENSHTEIN && (a.rowsA == 1 || a.rowsB == 1) && !a.no_literal_path) {
-        // a column against a literal (strsim_lane_lit.h): the literal is the wave-uniform text, the column is staged
-        const bool litA = a.rowsA == 1 && a.rowsB != 1;
+    // a column against a literal (strsim_lane_lit.h): the literal is the wave-uniform text, the column is staged -- either side
+    // for the symmetric measures, only a literal a for Jaro / Jaro-Winkler (they walk a)
+    const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
+    const bool lit_path = (M == JARO || M == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
+    if (a.stage_grid > 0 && lit_path && !a.no_literal_path) {
+        const bool litA = lit_a;
         const uint64_t nlb = (a.n + (LIT_ROWS - 1)) / LIT_ROWS;
         const uint64_t want = (uint64_t)a.stage_grid * 3u; // ~15 workgroups per CU in the launch, 5 resident
         const uint64_t gl = nlb < want ? nlb : want;
-        hipLaunchKernelGGL(k_lane_lit_lev, dim3((unsigned)gl), dim3(LIT_BLOCK), 0, a.stream, litA ? a.offB : a.offA,
+        hipLaunchKernelGGL((k_lane_lit<M>), dim3((unsigned)gl), dim3(LIT_BLOCK), 0, a.stream, litA ? a.offB : a.offA,
                            litA ? a.valB : a.valA, litA ? a.offA : a.offB, litA ? a.valA : a.valB, a.out, a.n, a.slowmask,
                            a.status, a.qtab);
     } else if (a.stage_grid > 0) {

@@ -1,6 +1,9 @@
-// strsim_lane_lit.h -- k_lane_lit_lev: Levenshtein of a COLUMN against ONE LITERAL (strsim.rs:48-52, :61-66, :85-92: either
-// side of the expression may be a Utf8 literal that is broadcast over the rows), one pair per lane, for literals and
-// column strings of <= 32 ASCII bytes.  Included by strsim_kernels.hip inside namespace strsim, after strsim_lane_stage.h.
+// strsim_lane_lit.h -- k_lane_lit<M>: a COLUMN against ONE LITERAL (strsim.rs:48-52, :61-66, :85-92: either side of the
+// expression may be a Utf8 literal that is broadcast over the rows), one pair per lane, for literals and column strings of
+// <= 32 ASCII bytes.  Included by strsim_kernels.hip inside namespace strsim, after strsim_lane_stage.h.
+// Levenshtein, Jaccard and Sorensen-Dice are symmetric, so the literal may be on either side; Jaro and Jaro-Winkler walk a
+// (strsim.rs:200-237), so they come here only when the literal IS a -- a literal b goes through k_lane_stage, sorted by the
+// column's lengths.
 //
 // What a literal buys, in the terms of the issue-cost table of bench_support/micro/op_cost.hip:
 //   * the literal is the TEXT the recurrence walks: every lane runs exactly len(literal) columns -- no sort by column
@@ -9,8 +12,9 @@
 //     cycles) are s_bfe_i32 on the scalar unit: a column costs 39 cycles of vector issue instead of 59;
 //   * only ONE column is staged through LDS (double-buffered: the bytes of block j+1 and the offsets of block j+2 are in
 //     flight while block j computes) and there is one workgroup barrier per block.
-// The column string of a row is the pattern (its bit-planes are built per row, as in k_lane_stage); the distance is
-// symmetric, so this serves literal-on-the-left and literal-on-the-right alike.  Rows this kernel cannot take (longer,
+// The column string of a row is the pattern (its bit-planes are built per row, as in k_lane_stage).  The other measures run
+// lane_cores32 (strsim_lane_core.h) on the same uniform text; their integers wait in LDS as 32-bit words and the f64
+// epilogue runs in the store phase, as in k_lane_stage.  Rows this kernel cannot take (longer,
 // non-ASCII, a single chunk overflowing the staging area) and every row of a call whose literal is longer than 32 bytes
 // or non-ASCII stay in the mask for the later kernels.
 #pragma once
@@ -58,21 +62,29 @@ __device__ __forceinline__ uint32_t lit_lev_uniform_text(const uint32_t (&wt)[8]
     return lt + popc32(Pl & rows) - popc32(Ml & rows);
 }
 
+// offC / valC: the column; offL / valL: the literal (one row).  Jaro, Jaro-Winkler: the literal is a, the column b.
+template <int MEASURE>
 __global__ __launch_bounds__(LIT_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_LIT_WAVES_PER_EU))) void
-k_lane_lit_lev(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, const uint32_t *__restrict__ offL,
-               const uint8_t *__restrict__ valL, double *__restrict__ out, uint64_t n, unsigned long long *__restrict__ slowmask,
-               DevStatus *__restrict__ status, const double *__restrict__ qtab)
+k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, const uint32_t *__restrict__ offL,
+           const uint8_t *__restrict__ valL, double *__restrict__ out, uint64_t n, unsigned long long *__restrict__ slowmask,
+           DevStatus *__restrict__ status, const double *__restrict__ qtab)
 {
+    constexpr bool LEV = MEASURE == LEVENSHTEIN;
+    constexpr bool JARO_LIKE = MEASURE == JARO || MEASURE == JARO_WINKLER;
     constexpr int B = LIT_ROWS, RPT = LIT_RPT;
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2][LIT_COL];
     __shared__ __attribute__((aligned(16))) uint32_t s_off[3][B + 4];
-    __shared__ uint16_t s_code[2][B];
+    __shared__ uint16_t s_code[LEV ? 2 : 1][LEV ? B : 1];  // Levenshtein: index into the quotient table
+    __shared__ uint32_t s_word[LEV ? 1 : 2][LEV ? 1 : B];  // the other measures: their integers (stage_ints' packing)
     __shared__ uint32_t s_lit[8];
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
 #pragma unroll
-    for (int q = 0; q < 2 * RPT; ++q) (&s_code[0][0])[(uint32_t)q * LIT_BLOCK + tid] = 0xFFFFu; // both buffers
+    for (int q = 0; q < 2 * RPT; ++q) { // both buffers
+        if (LEV) (&s_code[0][0])[(uint32_t)q * LIT_BLOCK + tid] = 0xFFFFu;
+        else (&s_word[0][0])[(uint32_t)q * LIT_BLOCK + tid] = 0xFFFFFFFFu;
+    }
     const uint32_t totalC = load_invariant(offC + n);
     const uint32_t lit0 = load_invariant(offL), litl = load_invariant(offL + 1) - lit0;
     if (wv == 0u) {
@@ -141,17 +153,44 @@ k_lane_lit_lev(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ va
         if (tid < 2u) *reinterpret_cast<uint4 *>(&s_bytes[buf][(chunks << 4) + tid * 16u]) = make_uint4(0u, 0u, 0u, 0u);
         return staged;
     };
+    // results of a block, coalesced; straight-line passes as in k_lane_stage (all table loads of a thread before the first wait)
+    auto pin = [](double &x) { asm volatile("" : "+v"(x)); };
     auto store_block = [&](uint64_t r0, uint32_t rows, uint32_t buf) {
         double *__restrict__ const outb = out + r0;
         unsigned long long *__restrict__ const maskb = slowmask + (r0 >> 6);
+        uint32_t pk[RPT];
+        double t0[RPT], t1[RPT], t2[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t i = (uint32_t)q * LIT_BLOCK + tid;
+            if (LEV) { pk[q] = s_code[LEV ? buf : 0u][LEV ? i : 0u]; s_code[LEV ? buf : 0u][LEV ? i : 0u] = 0xFFFFu; }
+            else { pk[q] = s_word[LEV ? 0u : buf][LEV ? 0u : i]; s_word[LEV ? 0u : buf][LEV ? 0u : i] = 0xFFFFFFFFu; }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (LEV) {
+                t0[q] = qtab[pk[q] == 0xFFFFu ? 0u : pk[q]]; // 1.0 - dist / den (strsim.rs:160) with the context's quotient table
+            } else if (JARO_LIKE) {
+                const uint32_t m = pk[q] & 63u, t = (pk[q] >> 6) & 63u, la = (pk[q] >> 12) & 63u, lb = (pk[q] >> 18) & 63u, h = t >> 1;
+                t0[q] = qtab[m * (uint32_t)QTAB_N + la];
+                t1[q] = qtab[m * (uint32_t)QTAB_N + lb];
+                t2[q] = qtab[(m > h ? m - h : 0u) * (uint32_t)QTAB_N + m];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (LEV || JARO_LIKE) pin(t0[q]);
+            if (JARO_LIKE) { pin(t1[q]); pin(t2[q]); }
+        }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const uint32_t i = (uint32_t)q * LIT_BLOCK + tid;
             if ((uint32_t)q * LIT_BLOCK < rows) { // (uniform)
-                const uint32_t code = s_code[buf][i];
-                s_code[buf][i] = 0xFFFFu;
-                const bool undone = code == 0xFFFFu, valid = i < rows;
-                const double v = 1.0 - qtab[undone ? 0u : code]; // strsim.rs:160 with the context's quotient table
+                const bool undone = pk[q] == (LEV ? 0xFFFFu : 0xFFFFFFFFu), valid = i < rows;
+                constexpr int M1 = LEV ? JARO : MEASURE;
+                double v = 0.0;
+                if (LEV) v = 1.0 - t0[q];
+                else if (!undone) v = stage_epilogue<M1>(pk[q], t0[q], t1[q], t2[q]);
                 const unsigned long long left = __ballot(undone && valid);
                 if (valid && !undone) outb[i] = v;
                 if (lane == 0u && valid) maskb[i >> 6] = left;
@@ -202,24 +241,52 @@ k_lane_lit_lev(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ va
             if (any & 0x80u) fast = false;
             if (__ballot(fast) == 0ull) continue;
             const bool wide = __ballot(fast && (vary & 0x60u)) != 0ull;
-            uint32_t code;
-            if (litl == 0u) { // an empty literal: 1.0 against an empty string, else 0.0 (strsim.rs:128, :160)
-                code = lp == 0u ? 1u : (uint32_t)QTAB_N + 1u;
-            } else {
-                const uint32_t lp1 = lp ? lp : 1u;
-                uint32_t dist;
-                if (wide) {
-                    uint32_t P[7];
-                    build_planes<7>(wp, P);
-                    dist = lit_lev_uniform_text<7>(wt, litl, P, lp1);
+            if (LEV) {
+                uint32_t code;
+                if (litl == 0u) { // an empty literal: 1.0 against an empty string, else 0.0 (strsim.rs:128, :160)
+                    code = lp == 0u ? 1u : (uint32_t)QTAB_N + 1u;
                 } else {
-                    uint32_t P[5];
-                    build_planes<5>(wp, P);
-                    dist = lit_lev_uniform_text<5>(wt, litl, P, lp1);
+                    const uint32_t lp1 = lp ? lp : 1u;
+                    uint32_t dist;
+                    if (wide) {
+                        uint32_t P[7];
+                        build_planes<7>(wp, P);
+                        dist = lit_lev_uniform_text<7>(wt, litl, P, lp1);
+                    } else {
+                        uint32_t P[5];
+                        build_planes<5>(wp, P);
+                        dist = lit_lev_uniform_text<5>(wt, litl, P, lp1);
+                    }
+                    code = lp ? dist * (uint32_t)QTAB_N + (litl > lp ? litl : lp) : (uint32_t)QTAB_N + 1u; // an empty column string: 0.0
                 }
-                code = lp ? dist * (uint32_t)QTAB_N + (litl > lp ? litl : lp) : (uint32_t)QTAB_N + 1u; // an empty column string: 0.0
+                if (fast) s_code[LEV ? bb : 0u][LEV ? i : 0u] = (uint16_t)code;
+            } else {
+                // text = the literal (for Jaro / Jaro-Winkler it is a), pattern = the column string: exactly litl columns for every
+                // lane, the bit fills of the uniform text on the scalar unit.  The integers as stage_ints packs them; an empty
+                // side is caught by the epilogue's early-outs (strsim.rs:182-186, :288-292, :324-328).
+                uint32_t dist = 0u, m = 0u, t = 0u, isect = 0u;
+                if (litl != 0u) { // (uniform)
+                    const uint32_t lp1 = lp ? lp : 1u;
+                    const uint32_t tmax = (litl + (uint32_t)COLS_PER_TEST - 1u) / (uint32_t)COLS_PER_TEST * (uint32_t)COLS_PER_TEST;
+                    if (wide) {
+                        uint32_t P[7];
+                        build_planes<7>(wp, P);
+                        lane_cores32<7, false, JARO_LIKE, !JARO_LIKE>(wt, litl, litl, tmax, lp1, P, dist, m, t, isect);
+                    } else {
+                        uint32_t P[5];
+                        build_planes<5>(wp, P);
+                        lane_cores32<5, false, JARO_LIKE, !JARO_LIKE>(wt, litl, litl, tmax, lp1, P, dist, m, t, isect);
+                    }
+                }
+                uint32_t pk;
+                if (JARO_LIKE) {
+                    const uint32_t pre = MEASURE == JARO_WINKLER && litl != 0u && lp != 0u ? common_prefix4(wt[0], litl, wp[0], lp) : 0u;
+                    pk = m | (t << 6) | (litl << 12) | (lp << 18) | (pre << 24);
+                } else {
+                    pk = isect | (litl << 6) | (lp << 12);
+                }
+                if (fast) s_word[LEV ? 0u : bb][LEV ? 0u : i] = pk;
             }
-            if (fast) s_code[bb][i] = (uint16_t)code;
         }
         prev_row0 = row0;
         prev_rows = rows;

@@ -246,9 +246,10 @@ __device__ __forceinline__ double stage_epilogue(uint32_t pk, double qa, double 
     return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
 }
 
+// `last`: the round's last lane that holds a row of this kernel (uniform)
 template <int MEASURE>
-__device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta, uint16_t *s_code,
-                                              uint32_t *s_word, double *s_val)
+__device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta, uint32_t last,
+                                              uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
@@ -259,9 +260,13 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
     if (any & 0x80u) fast = false;
     if (__ballot(fast) == 0ull) return;
     const uint32_t la = fast ? lt : 0u, lb = fast ? lp : 0u;
-    const uint32_t tmax = wave_max_rounded(la);
+    // the round's rows come in bucket order (2^STAGE_BSH text lengths per bucket): its last row's bucket bounds the longest
+    // text from above (exactly, up to the rounding to whole column groups that the cores do anyway), its first row's bucket
+    // the shortest from below -- two v_readlane instead of a ballot search
+    static_assert((1 << STAGE_BSH) % COLS_PER_TEST == 0, "a bucket's upper bound is a whole number of column groups");
+    const uint32_t ltl = (uint32_t)__builtin_amdgcn_readlane((int)lt, (int)last);
+    const uint32_t tmax = (((ltl ? ltl : 1u) - 1u) | ((1u << STAGE_BSH) - 1u)) + 1u;
     const bool wide = __ballot(fast && (vary & 0x60u)) != 0ull; // six-plane rounds run as seven (register budget)
-    // the round's rows come in bucket order (two text lengths per bucket), so its first row bounds the shortest text
     const uint32_t lt0 = uniform(lt);
     const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
     if (MEASURE == LEVENSHTEIN) {
@@ -338,18 +343,22 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     const uint32_t litA0 = bcastA ? load_invariant(offA) : 0u, litB0 = bcastB ? load_invariant(offB) : 0u;
     const uint32_t litAlen = bcastA ? totalA - litA0 : 0u, litBlen = bcastB ? totalB - litB0 : 0u;
     if (wv == 0u) {
-        // the literals' 32-byte windows, zero-padded, behind the two staging areas
-        uint32_t w[8];
-        if (bcastA) {
-            load_window32(valA, litA0, totalA, w);
+        // the literals' 32-byte windows behind the two staging areas, padded with copies of the literal's first byte: the
+        // bytes behind a string are never compared, but they take part in the test of which bit-planes tell a round's bytes
+        // apart, and zeros there would ask for seven planes in every round
+        auto literal_window = [&](const uint8_t *val, uint32_t at, uint32_t total, uint32_t len, uint32_t *dst) {
+            uint32_t w[8];
+            load_window32(val, at, total, w);
+            const uint32_t rep = (w[0] & 0xFFu) * 0x01010101u;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t *>(s_bytes + LIT)[q] = w[q];
-        }
-        if (bcastB) {
-            load_window32(valB, litB0, totalB, w);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t *>(s_bytes + LIT + 32u)[q] = w[q];
-        }
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t v = len > 4u * q ? (len - 4u * q < 4u ? len - 4u * q : 4u) : 0u; // bytes of this dword that are text
+                const uint32_t keep = v >= 4u ? 0xFFFFFFFFu : ((1u << (8u * v)) - 1u);
+                dst[q] = (w[q] & keep) | (rep & ~keep);
+            }
+        };
+        if (bcastA) literal_window(valA, litA0, totalA, litAlen, reinterpret_cast<uint32_t *>(s_bytes + LIT));
+        if (bcastB) literal_window(valB, litB0, totalB, litBlen, reinterpret_cast<uint32_t *>(s_bytes + LIT + 32u));
     }
     // Work distribution: ranges of 64-row chunks handed out by a device-wide counter (sched[0]; sched[1] counts the
     // workgroups that have finished, the last one clears both for the next launch).  A static split would do if all
@@ -660,7 +669,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             STAGE_STAMP(7);
-            stage_compute<MEASURE>(wt, wp, d.y, s_code, s_word, s_val);
+            const uint32_t in_round = nmine - r * 64u; // (>= 1)
+            stage_compute<MEASURE>(wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
             STAGE_STAMP(8);
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands

@@ -196,17 +196,18 @@ def test_literal_broadcast(S, ctx, measure):
         assert_bit_exact(got, O.batch_strings(measure, [lit], B, 4), [lit], B, measure + " lit,col")
 
 
-def test_literal_against_every_row_class(S, ctx):
-    """The column-x-literal kernel (k_lane_lit_lev) on a frame that mixes everything: short ASCII, empty strings, non-ASCII,
-    33..900-byte rows (blocks get cut to the staging area), more rows than one range; literal on either side."""
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_literal_against_every_row_class(S, ctx, measure):
+    """The column-x-literal kernel (k_lane_lit<M>; for Jaro / Jaro-Winkler only a literal a goes there, a literal b runs in
+    k_lane_stage) on a frame that mixes everything: short ASCII, empty strings, non-ASCII, 33..900-byte rows (blocks get cut to
+    the staging area), more rows than one range; literal on either side; empty, long and non-ASCII literals."""
     A, _ = gen.pairs(61, 150_000, gen.ASCII_LOWER, 0, 32)
     A2, _ = gen.pairs(62, 3000, gen.MIXED, 0, 120)
     A3, _ = gen.pairs(63, 300, gen.ASCII_LOWER, 200, 900)
     A = A[:70_000] + A2 + A[70_000:] + A3 + ["", "phillips", "a" * 32]
-    for lit in ("phillips", "sm", "abcdefghijklmnopqrstuvwxyzabcde"):
-        exp = O.batch_strings("levenshtein", A, [lit], 8)
-        assert_bit_exact(gpu(S, ctx, "levenshtein", A, [lit]), exp, A, [lit], "col,lit " + lit)
-        assert_bit_exact(gpu(S, ctx, "levenshtein", [lit], A), exp, [lit], A, "lit,col " + lit)
+    for lit in ("phillips", "sm", "abcdefghijklmnopqrstuvwxyzabcde", "", "a", "Phillips-Van Heusen 1881", "m\u00fcller", "x" * 40):
+        assert_bit_exact(gpu(S, ctx, measure, A, [lit]), O.batch_strings(measure, A, [lit], 8), A, [lit], measure + " col,lit " + lit)
+        assert_bit_exact(gpu(S, ctx, measure, [lit], A), O.batch_strings(measure, [lit], A, 8), [lit], A, measure + " lit,col " + lit)
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
