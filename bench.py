@@ -170,24 +170,40 @@ def main():
     gather_note = None
     if gather:
         from strsim_amd.distributed import ShardGatherer, gather_column
+        def agree(ok):  # every rank takes the same decision: MIN over the ranks' flags (a collective every rank reaches)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        # (1) the fallible NON-collective setup first, agreed on before any rank enters a gather: a rank that failed here must
+        #     not skip a collective the others are already inside (mismatched collectives hang on RCCL)
         ok = 1
         try:
             # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
             shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend, parts=shards,
                                     codec_chars=32 if ((hi <= 32 or a.force_codec) and not a.no_codec) else None)
-            # preflight, outside any timing: one tiny gather over the same call path builds the communicator (so that it is
-            # not built inside the timed region when --warmup is 0) and shows whether this backend can gather at all
             probe = torch.zeros(64, dtype=torch.uint8, device="cpu" if shipper.host else dev)
-            gather_column(probe, world * 64, dst=0)
-            torch.cuda.synchronize()
         except Exception as e:  # reported in the JSON line (gather_f64_to_rank0 false + gather_note), never silent
             ok = 0
-            gather_note = "gather disabled after a failed preflight: " + repr(e)[:300]
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:  # every rank takes the same decision
+            gather_note = "gather disabled: its setup failed: " + repr(e)[:300]
+        if not agree(ok):
             gather, shipper = False, None
-            gather_note = gather_note or "gather disabled: the preflight failed on another rank"
+            gather_note = gather_note or "gather disabled: its setup failed on another rank"
+        else:
+            # (2) preflight, outside any timing, entered by ALL ranks together: one tiny gather over the same call path builds
+            #     the communicator (so that it is not built inside the timed region when --warmup is 0) and shows whether this
+            #     backend can gather at all.  (A collective that throws on some ranks only leaves no safe way on: the flags below
+            #     are still exchanged, and a rank that cannot reach that exchange fails the job loudly instead of hanging it.)
+            ok = 1
+            try:
+                gather_column(probe, world * 64, dst=0)
+                torch.cuda.synchronize()
+            except Exception as e:
+                ok = 0
+                gather_note = "gather disabled after a failed preflight: " + repr(e)[:300]
+            if not agree(ok):
+                gather, shipper = False, None
+                gather_note = gather_note or "gather disabled: the preflight failed on another rank"
+        if not gather:
             print(f"[bench rank {rank}] {gather_note}", file=sys.stderr)
     fused = len(measures) == 5  # cfg4: strsim_pairs_device_all, one fused pass with five outputs
 
