@@ -844,6 +844,12 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         prev_rows = want;
         return want;
     };
+    // whatever goes wrong below (a failed launch, a string beyond 4 GiB in a later slice): nothing of this call may still be in
+    // flight when the error leaves the plugin -- the slots are reused by the next call and the output column is released
+    struct Drain {
+        strsim_ctx_t *ctx; hipStream_t d2h; bool armed = true;
+        ~Drain() { if (armed) { (void)strsim_ctx_synchronize(ctx); (void)hipStreamSynchronize(d2h); } }
+    } drain{ctx, g_ctx.d2h};
     uint64_t r0 = lo;
     unsigned k = 0;
     tm.start(); r0 += pack(g_ctx.slot[0], r0, next_rows(r0)); tm.stop(tm.t_pack);
@@ -856,6 +862,7 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         ++k;
     }
     finish(g_ctx.slot[k % 3]);
+    drain.armed = false;
 }
 
 void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)

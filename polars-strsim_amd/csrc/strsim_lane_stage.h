@@ -57,7 +57,10 @@ __device__ unsigned long long g_stage_stamps[16384][16]; // [12], [13]: s_memrea
 #define STAGE_STAMP(cat) do { } while (0)
 #endif
 
-constexpr int STAGE_BLOCK = 256;                      // threads per workgroup
+#ifndef STRSIM_STAGE_THREADS
+#define STRSIM_STAGE_THREADS 256
+#endif
+constexpr int STAGE_BLOCK = STRSIM_STAGE_THREADS;     // threads per workgroup
 constexpr int STAGE_WAVES = STAGE_BLOCK / 64;         // 4
 constexpr int STAGE_ROWS = STRSIM_STAGE_ROWS;         // rows per block
 constexpr int STAGE_RPT = STAGE_ROWS / STAGE_BLOCK;   // rows per thread in the coalesced phases
