@@ -146,6 +146,13 @@ STRSIM_API int strsim_ctx_timing_enable(strsim_ctx_t *ctx, int enable);
 STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms, uint64_t *lane_kernel_launches,
                            double *wave_kernel_ms, uint64_t *wave_kernel_launches);
 
+/* Offsets of a column from its string LENGTHS, on the device: offsets[0] = 0, offsets[i + 1] = offsets[i] + lengths[i]
+ * (lengths: `rows` bytes on the device, 16-byte aligned; offsets: rows + 1 words).  Asynchronous on the context's stream.
+ * For a host that holds strings as views / (pointer, length) pairs (Polars' Utf8View, the layout the reference iterates at
+ * strsim.rs:46-47) and ships one length byte per row over PCIe instead of a u32 offset; strings of at most 255 bytes, at
+ * most 2^26 rows per call.  The result is what strsim_pairs_device() takes as a_offsets / b_offsets. */
+STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets);
+
 /* For a caller that keeps several calls in flight on the context's stream and learns of their completion by its own means
  * (an event recorded on strsim_ctx_stream() behind each call): retire the OLDEST pending call only -- what
  * strsim_ctx_synchronize() does for all of them, without waiting for the younger ones.  The caller guarantees that the

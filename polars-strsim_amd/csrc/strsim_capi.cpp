@@ -80,6 +80,7 @@ struct strsim_ctx {
     size_t lev_ws_cap = 0;
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
+    uint32_t *scan_ws = nullptr;     // block sums of strsim_offsets_from_lengths (SCAN_WS_WORDS, allocated on first use)
     int head = 0;
     double *qtab = nullptr;          // QTAB_N x QTAB_N quotients a / b (strsim_lane_core.h), filled at creation
     uint64_t last_wave_rows = 0;
@@ -284,6 +285,7 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
     if (c->qtab) (void)hipFree(c->qtab);
     if (c->sched) (void)hipFree(c->sched);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->lev_ws) (void)hipFree(c->lev_ws);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
@@ -458,6 +460,15 @@ int strsim_ctx_synchronize(strsim_ctx_t *c)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ctx_drain(c);
+}
+
+int strsim_internal_scan_workspace(strsim_ctx *c, uint32_t **p)
+{
+    int rc = ctx_set_device(c);
+    if (rc) return rc;
+    if (!c->scan_ws) HIP_TRY(hipMalloc((void **)&c->scan_ws, strsim::SCAN_WS_WORDS * sizeof(uint32_t)));
+    *p = c->scan_ws;
+    return STRSIM_OK;
 }
 
 int strsim_ctx_retire_oldest(strsim_ctx_t *c)

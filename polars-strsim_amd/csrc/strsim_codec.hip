@@ -211,6 +211,89 @@ __global__ void k_patch_indirect(double *__restrict__ out, uint64_t row_base, co
         out[row_base + rows[i]] = vals[i];
 }
 
+// ---- offsets from lengths -------------------------------------------------------------------------------------------
+// The host ships a column's string LENGTHS as one byte per row (strings of at most 255 bytes) instead of its u32 offsets --
+// 35 instead of 41 bytes per pair over PCIe for cfg2's lengths -- and the offsets are rebuilt here: offsets[0] = 0,
+// offsets[i + 1] = offsets[i] + lengths[i].  Two launches: sums of blocks of LEN_ROWS rows, then every workgroup adds up the
+// sums in front of its block (at most SCAN_WS_WORDS of them, L2-resident) and scans its own rows.
+constexpr int LEN_THREADS = 256, LEN_PER_THREAD = 16, LEN_ROWS = LEN_THREADS * LEN_PER_THREAD;
+
+// the 16 lengths of thread `t` of the block that starts at row r0 (zeros behind the last row), as four dwords
+__device__ __forceinline__ uint4 load_lengths16(const uint8_t *__restrict__ len, uint64_t rows, uint64_t r0, uint32_t t)
+{
+    const uint64_t at = r0 + (uint64_t)t * LEN_PER_THREAD;
+    if (at + LEN_PER_THREAD <= rows) return *reinterpret_cast<const uint4 *>(len + at); // (len is 16-byte aligned, r0 a multiple of 4096)
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < LEN_PER_THREAD; ++k)
+        if (at + (uint64_t)k < rows) w[k >> 2] |= (uint32_t)len[at + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t sum_bytes16(uint4 v)
+{
+    uint32_t s = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
+    s = __builtin_amdgcn_sad_u8(v.y, 0u, s);
+    s = __builtin_amdgcn_sad_u8(v.z, 0u, s);
+    return __builtin_amdgcn_sad_u8(v.w, 0u, s);
+}
+
+// sum over the workgroup of one value per thread (every thread gets it)
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *s_part)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) s_part[wv] = v;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int w = 0; w < LEN_THREADS / 64; ++w) tot += s_part[w];
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(LEN_THREADS) void k_len_block_sums(const uint8_t *__restrict__ len, uint64_t rows, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t s_part[LEN_THREADS / 64];
+    const uint32_t tot = block_sum(sum_bytes16(load_lengths16(len, rows, (uint64_t)blockIdx.x * LEN_ROWS, threadIdx.x)), s_part);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(LEN_THREADS) void k_len_offsets(const uint8_t *__restrict__ len, uint64_t rows, const uint32_t *__restrict__ sums,
+                                                            uint32_t *__restrict__ off)
+{
+    __shared__ uint32_t s_part[LEN_THREADS / 64];
+    __shared__ uint32_t s_wave[LEN_THREADS / 64];
+    __shared__ uint32_t s_off[LEN_ROWS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * LEN_ROWS;
+    // bytes in front of this block
+    uint32_t mine = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += LEN_THREADS) mine += sums[b];
+    const uint32_t base = block_sum(mine, s_part);
+    // this thread's 16 rows: their total, its exclusive prefix over the workgroup, then the 16 running ends
+    const uint4 v = load_lengths16(len, rows, r0, tid);
+    const uint32_t tot = sum_bytes16(v);
+    uint32_t inc = tot;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += up;
+    }
+    if (lane == 63u) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t run = base + inc - tot;
+    for (uint32_t w = 0; w < wv; ++w) run += s_wave[w];
+    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < LEN_PER_THREAD; ++k) {
+        run += (w4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        s_off[tid * LEN_PER_THREAD + k] = run; // offsets[r0 + 16 tid + k + 1]
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) off[0] = 0u;
+    const uint64_t left = rows - r0;
+    const uint32_t cnt = left < (uint64_t)LEN_ROWS ? (uint32_t)left : (uint32_t)LEN_ROWS;
+    for (uint32_t i = tid; i < cnt; i += LEN_THREADS) off[r0 + i + 1] = s_off[i];
+}
+
 #define HIP_TRY(expr)                                          \
     do {                                                       \
         hipError_t e__ = (expr);                               \
@@ -325,6 +408,30 @@ int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint64_t row_bas
     if (!ctx || !out || !exc_count || !exc_rows || !exc_vals || !overflow) { set_error("strsim_codec_patch_indirect: NULL argument"); return STRSIM_ERR_ARG; }
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
     hipLaunchKernelGGL(k_patch_indirect, dim3(32), dim3(256), 0, st, out, row_base, exc_count, exc_rows, exc_vals, exc_cap, overflow);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets)
+{
+    if (!ctx || !offsets || (!lengths && rows)) { set_error("strsim_offsets_from_lengths: NULL argument"); return STRSIM_ERR_ARG; }
+    const uint64_t nblk = (rows + LEN_ROWS - 1) / LEN_ROWS;
+    if (nblk > strsim::SCAN_WS_WORDS) {
+        set_error("strsim_offsets_from_lengths: %llu rows in one call; at most %llu", (unsigned long long)rows,
+                  (unsigned long long)(strsim::SCAN_WS_WORDS * (uint64_t)LEN_ROWS));
+        return STRSIM_ERR_ARG;
+    }
+    if (reinterpret_cast<uintptr_t>(lengths) & 15u) { set_error("strsim_offsets_from_lengths: lengths must be 16-byte aligned"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    if (rows == 0) {
+        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(uint32_t), st));
+        return STRSIM_OK;
+    }
+    uint32_t *sums = nullptr;
+    const int rc = strsim_internal_scan_workspace(ctx, &sums);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_len_block_sums, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums);
+    hipLaunchKernelGGL(k_len_offsets, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums, offsets);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

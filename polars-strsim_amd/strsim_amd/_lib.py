@@ -106,6 +106,10 @@ def lib():
     L.strsim_codec_decode_packed.argtypes = [vp, vp, vp, u64, vp]
     L.strsim_codec_patch.restype = i32
     L.strsim_codec_patch.argtypes = [vp, vp, u64, vp, vp, C.c_uint32]
+    L.strsim_offsets_from_lengths.restype = i32
+    L.strsim_offsets_from_lengths.argtypes = [vp, vp, u64, vp]
+    L.strsim_ctx_retire_oldest.restype = i32
+    L.strsim_ctx_retire_oldest.argtypes = [vp]
     L.strsim_codec_patch_indirect.restype = i32
     L.strsim_codec_patch_indirect.argtypes = [vp, vp, u64, vp, vp, vp, C.c_uint32, vp]
     L.strsim_ctx_synchronize.restype = i32

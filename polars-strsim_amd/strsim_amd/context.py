@@ -91,6 +91,19 @@ class Context:
                                         out.data_ptr(), out.numel()))
         return out
 
+    def offsets_from_lengths(self, lengths, out=None):
+        """uint8 device tensor of string lengths -> uint32 offsets (rows + 1) on the device (strsim_offsets_from_lengths)."""
+        import torch
+        n = lengths.numel()
+        if out is None:
+            out = torch.empty(n + 1, dtype=torch.int32, device=lengths.device)
+        check(lib().strsim_offsets_from_lengths(self._h, lengths.data_ptr(), int(n), out.data_ptr()))
+        return out
+
+    def retire_oldest(self):
+        """Retire the oldest pending call only (the caller knows by an event of its own that it has completed)."""
+        check(lib().strsim_ctx_retire_oldest(self._h))
+
     def pairs_device_all(self, a_offsets, a_values, b_offsets, b_values, outs=None):
         """All five measures in one fused call -> list of five f64 tensors indexed like MEASURES."""
         import torch

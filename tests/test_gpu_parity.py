@@ -422,3 +422,43 @@ def test_transport_codec_rejects_oversized_tables(S):
         c = S.Codec(ctx, "levenshtein", 128)
         assert c.entries > 1000
         c.close()
+
+
+@pytest.mark.parametrize("rows", [0, 1, 15, 16, 17, 4095, 4096, 4097, 65536 + 5, 3_000_001])
+def test_offsets_from_lengths(S, ctx, rows):
+    """strsim_offsets_from_lengths: what the plugin ships instead of u32 offsets when every string is <= 255 bytes."""
+    import torch
+    rng = np.random.default_rng(rows + 1)
+    lens = rng.integers(0, 256, rows, dtype=np.uint8) if rows % 2 else rng.integers(0, 33, rows, dtype=np.uint8)
+    d = torch.from_numpy(lens).cuda()
+    off = ctx.offsets_from_lengths(d)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    exp = np.concatenate([[0], np.cumsum(lens.astype(np.uint64))]).astype(np.uint32)
+    assert np.array_equal(off.cpu().numpy().view(np.uint32), exp)
+
+
+def test_calls_in_flight_are_retired_one_at_a_time(S):
+    """strsim_ctx_retire_oldest: three calls enqueued back to back, each retired behind an event of the caller's own."""
+    import torch
+    A, B = gen.pairs(77, 30_000, gen.ASCII_LOWER, 0, 40)
+    exp = O.batch_strings("levenshtein", A, B, 8)
+    oa, va = S.pack_strings(A)
+    ob, vb = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    args = (t(oa, np.int32), t(np.concatenate([va, pad]), np.uint8), t(ob, np.int32), t(np.concatenate([vb, pad]), np.uint8))
+    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+        outs, evs = [], []
+        for _ in range(3):
+            outs.append(ctx.pairs_device("levenshtein", *args))
+            ev = torch.cuda.Event()
+            ev.record()
+            evs.append(ev)
+        for k in range(3):
+            evs[k].synchronize()
+            ctx.retire_oldest()
+            got = outs[k].cpu().numpy()
+            assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), k
+        ctx.synchronize()  # nothing left to retire
