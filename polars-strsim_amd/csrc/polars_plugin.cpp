@@ -115,18 +115,19 @@ inline bool row_valid(const Column &c, uint64_t r)
     return !k.nulls || bit_at(k.nulls, k.a->offset + (int64_t)(r - k.row0));
 }
 
-// packed byte count of rows [r0, r1); a null view slot counts as empty
-uint64_t range_bytes(const Column &c, uint64_t r0, uint64_t r1)
+// packed byte count of rows [r0, r1); a null view slot counts as empty.  maxlen (views only): the longest string of the range.
+uint64_t range_bytes(const Column &c, uint64_t r0, uint64_t r1, uint32_t *maxlen = nullptr)
 {
     uint64_t bytes = 0;
+    uint32_t mx = 0;
     for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
         const Chunk &k = c.chunks[ci];
         const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
         const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)k.a->length) - k.row0);
         if (c.layout == L_VIEW) {
             const View *v = static_cast<const View *>(k.a->buffers[1]) + k.a->offset;
-            if (!k.nulls) for (int64_t i = i0; i < i1; ++i) bytes += v[i].len;
-            else for (int64_t i = i0; i < i1; ++i) if (bit_at(k.nulls, k.a->offset + i)) bytes += v[i].len;
+            if (!k.nulls) for (int64_t i = i0; i < i1; ++i) { bytes += v[i].len; mx = std::max(mx, v[i].len); }
+            else for (int64_t i = i0; i < i1; ++i) if (bit_at(k.nulls, k.a->offset + i)) { bytes += v[i].len; mx = std::max(mx, v[i].len); }
         } else if (c.layout == L_U32) {
             const int32_t *o = static_cast<const int32_t *>(k.a->buffers[1]) + k.a->offset;
             bytes += (uint64_t)(o[i1] - o[i0]);
@@ -135,12 +136,16 @@ uint64_t range_bytes(const Column &c, uint64_t r0, uint64_t r1)
             bytes += (uint64_t)(o[i1] - o[i0]);
         }
     }
+    if (maxlen) *maxlen = mx;
     return bytes;
 }
 
 // pack rows [r0, r1): off[i - r0 + 1] = end of row i (starting from `base`), bytes appended at val + base;
 // `limit` = end of this range's bytes (another thread owns what follows)
-void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64_t base, uint64_t limit, uint8_t *val)
+// (views only) len8 != nullptr: one length byte per row goes to len8[0 ..] INSTEAD of the offsets (the device rebuilds them,
+// strsim_offsets_from_lengths); the caller has checked that no string of the range exceeds 255 bytes
+void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64_t base, uint64_t limit, uint8_t *val,
+                uint8_t *len8 = nullptr)
 {
     uint64_t pos = base;
     uint32_t *o_out = off + 1;
@@ -173,8 +178,11 @@ void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64
                     if (len <= 32 && room && pos + 32 <= limit) memcpy(val + pos, src, 32);
                     else memcpy(val + pos, src, len);
                     pos += len;
+                    if (len8) *len8 = (uint8_t)len;
+                } else if (len8) {
+                    *len8 = 0;
                 }
-                *o_out++ = (uint32_t)pos;
+                if (len8) ++len8; else *o_out++ = (uint32_t)pos;
             }
         } else {
             const uint8_t *data = static_cast<const uint8_t *>(a->buffers[2]);
@@ -491,14 +499,16 @@ struct Buf {
 // one pipeline slot: a slice of both columns packed in pinned memory + its device mirror + its results
 struct Slot {
     Buf h_off[2], h_val[2], h_out, d_off[2], d_val[2], d_out;
+    Buf h_len[2], d_len[2]; // one length byte per row, shipped instead of the offsets when lens8[s] (see pack_slice2)
+    bool lens8[2] = {false, false};
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
     bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
     hipEvent_t ev_kernels = nullptr, ev_results = nullptr; // behind the slice's kernels (compute stream) / its D2H (copy stream)
-    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; } d_out.device = true; }
+    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; } d_out.device = true; }
     void release()
     {
-        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); }
+        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); }
         h_out.release(); d_out.release();
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev_results) (void)hipEventDestroy(ev_results);
@@ -659,28 +669,40 @@ uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &va
 
 // the same for BOTH columns of a slice in two jobs instead of four (sizes of both, then bytes of both): thread t takes rows
 // lo(t) .. lo(t+1) of each column.  bytes[s] = packed byte count; false when a column's bytes exceed SLICE_BYTES.
-bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Buf (&off)[2], Buf (&val)[2], uint64_t (&bytes)[2], unsigned T)
+bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, bool allow_lens8, unsigned T)
 {
+    Buf (&off)[2] = sl.h_off, (&val)[2] = sl.h_val;
+    uint64_t (&bytes)[2] = sl.bytes;
     const uint64_t rows = r1 - r0;
     T = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(rows / 16384, 1));
     std::vector<uint64_t> part[2] = {std::vector<uint64_t>(T + 1, 0), std::vector<uint64_t>(T + 1, 0)};
+    std::vector<uint32_t> mx[2] = {std::vector<uint32_t>(T, 0), std::vector<uint32_t>(T, 0)};
     auto lo = [&](unsigned t) { return r0 + rows * t / T; };
-    fork_join(T, [&](unsigned t) { for (int s = 0; s < 2; ++s) part[s][t + 1] = range_bytes(col[s], lo(t), lo(t + 1)); });
+    fork_join(T, [&](unsigned t) { for (int s = 0; s < 2; ++s) part[s][t + 1] = range_bytes(col[s], lo(t), lo(t + 1), &mx[s][t]); });
     for (int s = 0; s < 2; ++s) {
         for (unsigned t = 0; t < T; ++t) part[s][t + 1] += part[s][t];
         bytes[s] = part[s][T];
+        // a column of views whose strings all fit a byte ships LENGTHS (1 B per row instead of a 4-byte offset over PCIe)
+        sl.lens8[s] = allow_lens8 && col[s].layout == L_VIEW && *std::max_element(mx[s].begin(), mx[s].end()) <= 255u;
     }
     if (bytes[0] > SLICE_BYTES || bytes[1] > SLICE_BYTES) return false;
-    uint32_t *o[2];
+    uint32_t *o[2] = {nullptr, nullptr};
+    uint8_t *l8[2] = {nullptr, nullptr};
     for (int s = 0; s < 2; ++s) {
-        off[s].reserve((rows + 1) * sizeof(uint32_t));
         val[s].reserve(bytes[s] + 64);
-        o[s] = static_cast<uint32_t *>(off[s].p);
-        o[s][0] = 0;
+        if (sl.lens8[s]) {
+            sl.h_len[s].reserve(rows + 16);
+            l8[s] = static_cast<uint8_t *>(sl.h_len[s].p);
+        } else {
+            off[s].reserve((rows + 1) * sizeof(uint32_t));
+            o[s] = static_cast<uint32_t *>(off[s].p);
+            o[s][0] = 0;
+        }
     }
     fork_join(T, [&](unsigned t) {
         for (int s = 0; s < 2; ++s)
-            pack_range(col[s], lo(t), lo(t + 1), o[s] + (lo(t) - r0), part[s][t], part[s][t + 1], static_cast<uint8_t *>(val[s].p));
+            pack_range(col[s], lo(t), lo(t + 1), o[s] ? o[s] + (lo(t) - r0) : nullptr, part[s][t], part[s][t + 1],
+                       static_cast<uint8_t *>(val[s].p), l8[s] ? l8[s] + (lo(t) - r0) : nullptr);
     });
     return true;
 }
@@ -733,13 +755,17 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
     }
 
+    // (slices computed in place read their offsets from the pinned staging; POLARS_STRSIM_LENGTH_BYTES=0: always ship offsets)
+    static const bool lens8_env = [] { const char *e = getenv("POLARS_STRSIM_LENGTH_BYTES"); return !e || atoi(e) != 0; }();
+    const bool lens8_ok = lens8_env && !direct_call;
     // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
     auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
         uint64_t rows = std::min<uint64_t>(want, hi - r0);
         for (;;) {
             bool fits = true;
+            sl.lens8[0] = sl.lens8[1] = false;
             if (!lit[0] && !lit[1]) {
-                fits = pack_slice2(col, r0, r0 + rows, sl.h_off, sl.h_val, sl.bytes, T);
+                fits = pack_slice2(col, r0, r0 + rows, sl, lens8_ok, T);
             } else {
                 for (int s = 0; s < 2 && fits; ++s) {
                     if (lit[s]) continue;
@@ -771,7 +797,14 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
             }
             sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
             sl.d_val[s].reserve(sl.bytes[s] + 64);
-            HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            if (sl.lens8[s]) { // lengths over the link, offsets rebuilt on the device
+                sl.d_len[s].reserve(sl.rows + 16);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_len[s].p, sl.h_len[s].p, sl.rows, hipMemcpyHostToDevice, stream));
+                if (strsim_offsets_from_lengths(ctx, static_cast<const uint8_t *>(sl.d_len[s].p), sl.rows, static_cast<uint32_t *>(sl.d_off[s].p)) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+            } else {
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            }
             if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
             doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
             dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
