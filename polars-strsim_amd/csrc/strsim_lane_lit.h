@@ -227,6 +227,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         // ---- results of block j-1
         if (prev_rows) store_block(prev_row0, prev_rows, bb ^ 1u);
         // ---- rounds(j): rows in their natural order, round r on wave r % 4
+        __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
         for (uint32_t r = wv; r * 64u < rows; r += LIT_WAVES) {
             const uint32_t i = r * 64u + lane;
             const bool have = i < rows;
@@ -288,6 +289,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
                 if (fast) s_word[LEV ? 0u : bb][LEV ? 0u : i] = pk;
             }
         }
+        __builtin_amdgcn_s_setprio(1);
         prev_row0 = row0;
         prev_rows = rows;
         prev_bb = bb;

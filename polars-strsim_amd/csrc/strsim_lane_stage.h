@@ -40,6 +40,15 @@
 #define STRSIM_STAGE_BUCKET_SHIFT 1
 #endif
 
+#ifndef STRSIM_STAGE_PRIO
+#define STRSIM_STAGE_PRIO 1
+#endif
+#ifndef STRSIM_STAGE_PRIO_WINDOWS
+#define STRSIM_STAGE_PRIO_WINDOWS 1
+#endif
+#ifndef STRSIM_STAGE_PRIO_PLANES
+#define STRSIM_STAGE_PRIO_PLANES 0
+#endif
 #ifndef STRSIM_STAGE_STORE_FIRST
 #define STRSIM_STAGE_STORE_FIRST 1
 #endif
@@ -163,6 +172,9 @@ __device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
+#if STRSIM_STAGE_PRIO_PLANES
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
     const uint32_t dist = lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
@@ -653,6 +665,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         if (next_row0 < row_end) dma_offsets(next_row0);
         STAGE_STAMP(6);
         // ---- F: rounds(j): wave w runs rounds w, 2W-1-w, 2W+w, ... of the length order (short + long = balanced)
+#if STRSIM_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
+#endif
 #pragma unroll 1
         for (int k = 0; k < STAGE_RPW; ++k) {
             const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
@@ -664,6 +679,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #ifdef STRSIM_EXP_NOROUNDS
             if (nmine != 0x12345u) continue;
 #endif
+#if STRSIM_STAGE_PRIO_WINDOWS
+            __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
+#endif
             const uint2 d = s_desc[r * 64u + lane];
             uint32_t wt[8], wp[8];
             stage_window(s_bytes, d.x & 0xFFFFu, wt);
@@ -672,11 +690,17 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             STAGE_STAMP(7);
+#if STRSIM_STAGE_PRIO_WINDOWS && !STRSIM_STAGE_PRIO_PLANES
+            __builtin_amdgcn_s_setprio(0);
+#endif
             const uint32_t in_round = nmine - r * 64u; // (>= 1)
             stage_compute<MEASURE>(wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
             STAGE_STAMP(8);
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
+#if STRSIM_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         STAGE_STAMP(9);
