@@ -228,8 +228,8 @@ class PinnedPool {
   public:
     void *acquire(size_t bytes)
     {
-        static const bool off = [] { const char *e = getenv("POLARS_STRSIM_PINNED_OUT"); return e && atoi(e) == 0; }();
-        if (off || bytes < PINNED_OUT_MIN_BYTES || bytes > PINNED_OUT_MAX_BYTES) return nullptr;
+        const char *e = getenv("POLARS_STRSIM_PINNED_OUT"); // (read per call: a large column, one getenv)
+        if ((e && atoi(e) == 0) || bytes < PINNED_OUT_MIN_BYTES || bytes > PINNED_OUT_MAX_BYTES) return nullptr;
         std::lock_guard<std::mutex> lk(m_);
         if (lent_ + bytes > PINNED_OUT_LENT_BYTES) return nullptr;
         int best = -1;
@@ -756,8 +756,8 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
     }
 
     // (slices computed in place read their offsets from the pinned staging; POLARS_STRSIM_LENGTH_BYTES=0: always ship offsets)
-    static const bool lens8_env = [] { const char *e = getenv("POLARS_STRSIM_LENGTH_BYTES"); return !e || atoi(e) != 0; }();
-    const bool lens8_ok = lens8_env && !direct_call;
+    const char *lens8_env = getenv("POLARS_STRSIM_LENGTH_BYTES");
+    const bool lens8_ok = !(lens8_env && atoi(lens8_env) == 0) && !direct_call;
     // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
     auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
         uint64_t rows = std::min<uint64_t>(want, hi - r0);

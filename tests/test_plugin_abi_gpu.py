@@ -194,3 +194,23 @@ def test_rows_shard_over_several_device_pipelines(H, monkeypatch, devices, min_r
     check(H.call_plugin("jaro", "philips", B), expect("jaro", ["philips"], B))
     monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
     check(H.call_plugin("sorensen_dice", A[:70000], B[:70000]), expect("sorensen_dice", A[:70000], B[:70000]))
+
+
+def test_large_call_with_and_without_pinned_result_and_length_bytes(H, monkeypatch):
+    """A multi-slice call (1.3 M rows): the result column in pooled pinned memory (default) or malloc'd + copied, offsets
+    shipped as one length byte per row (default) or as u32 -- the four combinations agree bit for bit, and match the oracle on
+    windows; a second call reuses the pool's block."""
+    A, B = gen.pairs(91, 1_300_000, gen.ASCII_LOWER, 0, 32)
+    A[7] = None
+    B[1_200_000] = "q" * 300  # one slice of column b falls back to u32 offsets
+    ref = None
+    for pinned, lens in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("POLARS_STRSIM_PINNED_OUT", pinned)
+        monkeypatch.setenv("POLARS_STRSIM_LENGTH_BYTES", lens)
+        got = H.call_plugin("levenshtein", A, B)
+        if ref is None:
+            ref = got
+            for lo in (0, 650_000, 1_199_000, 1_290_000):
+                check(got[lo:lo + 10_000], expect("levenshtein", A[lo:lo + 10_000], B[lo:lo + 10_000]))
+        else:
+            assert got.equals(ref), (pinned, lens)
