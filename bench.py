@@ -34,6 +34,9 @@ def parse():
     # headline kernel measures 1.89-1.93 ms, from --warmup 10 on 1.71-1.77 ms (same box, back to back)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--preheat-ms", type=float, default=40.0,
+                   help="untimed steps run BEFORE the --warmup steps until the GPU has been under this load for so long "
+                        "(clocks settle ~25-40 ms after idle; reported as config.preheat_steps; 0 = none)")
     p.add_argument("--config", default="cfg2", help="cfg1|cfg2|cfg3|cfg5 (BASELINE.json configs; cfg2 = headline)")
     p.add_argument("--rows", type=int, default=0, help="rows of the frame (strong) / per GPU (weak); default: the config's row count")
     p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -229,6 +232,25 @@ def main():
             shipper.drain()
         torch.cuda.synchronize()
 
+    # Preheat (disclosed in the JSON line): the first 25-40 ms after the GPU goes from idle to this load run ~5-10 % slower
+    # (clock ramp), which a short run (--warmup 5 --steps 20 is 35 ms) would measure instead of the steady state a 100 M-row
+    # job is in.  One step is timed to size the preheat; every rank runs the same number of steps (the gather is collective).
+    preheat_steps = 0
+    if a.preheat_ms > 0:
+        step(0)
+        drain()
+        t0 = time.perf_counter()
+        step(1)
+        drain()
+        one = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=(dev if a.backend == "nccl" else "cpu") if world > 1 else "cpu")
+        if world > 1:
+            dist.all_reduce(one, op=dist.ReduceOp.MAX)
+        preheat_steps = max(0, min(2000, int(a.preheat_ms * 1e-3 / max(float(one.item()), 1e-6)) + 1))
+        preheat_steps += preheat_steps & 1  # (an even count: the output / gather slots alternate with the step index)
+        for i in range(preheat_steps):
+            step(i)
+        drain()
+        preheat_steps += 2
     for i in range(a.warmup):
         step(i)
     drain()
@@ -304,7 +326,7 @@ def main():
             "dtype": "u8/u32 bit-parallel, f64 epilogue", "data": "synthetic",
             "config": {"workload": f"{a.config}: {measure}, {total_rows} rows ({a.scaling} scaling: {rows} on rank 0), lengths "
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
-                       "rows_total": total_rows, "rows_rank0": rows, "gather_f64_to_rank0": bool(gather),
+                       "rows_total": total_rows, "rows_rank0": rows, "preheat_steps": preheat_steps, "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
                        "gather_verified": gather_ok, "gather_note": gather_note,
