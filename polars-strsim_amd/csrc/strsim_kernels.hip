@@ -275,7 +275,7 @@ k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_wide: one pair per lane for the rows k_lane_pairs left behind whose strings are 33..128 ASCII
-// bytes: W = 2 (<= 64) or W = 4 (<= 128) word masks (strsim_lane_wide.h).  A workgroup takes a span of
+// bytes: W = 2 (<= 64), 3 (<= 96) or 4 (<= 128) word masks (strsim_lane_wide.h).  A workgroup takes a span of
 // WIDE_SPAN mask words (2048 rows), collects the flagged rows of each width class into LDS lists and runs
 // them 64 at a time; finished rows are cleared from the mask, the rest (non-ASCII, longer, empty side)
 // stay for k_wave_pairs.  With nothing flagged a span costs one 256-byte read.
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                                                           unsigned long long *__restrict__ slowmask, uint32_t sps)
 {
     __shared__ unsigned long long s_mask[WIDE_SPAN];
-    __shared__ uint32_t s_cnt[16];              // rows per key = width class (2) x column-count bucket (8)
+    __shared__ uint32_t s_cnt[24];              // rows per key = width class (3: <= 64, <= 96, <= 128 bytes) x column-count bucket (8)
     __shared__ uint32_t s_next;                 // next round to hand out
     __shared__ uint16_t s_list[WIDE_ROWS];      // candidate rows (index within the span), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
       for (uint64_t span = sup * sps; span < (sup + 1) * sps && span < nspans; ++span) {
         const uint64_t c0 = span * WIDE_SPAN;
         if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
-        if (tid < 16u) s_cnt[tid] = 0u;
-        if (tid == 16u) s_next = 0u;
+        if (tid < 24u) s_cnt[tid] = 0u;
+        if (tid == 24u) s_next = 0u;
         lds_barrier();
         const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                     const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
                     if (mx > 32u && mx <= 128u && mn >= 1u) {
                         const uint32_t steps = SYMMETRIC ? mn : la8;
-                        const uint32_t cls = mx > 64u ? 1u : 0u;
+                        const uint32_t cls = mx > 96u ? 2u : (mx > 64u ? 1u : 0u); // masks of 4 / 3 / 2 words
                         key[k] = cls * 8u + ((steps - 1u) >> (cls ? 4 : 3));
                         rank[k] = atomicAdd(&s_cnt[key[k]], 1u);
                     }
@@ -454,15 +454,15 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
             lds_barrier();
             uint32_t total = 0;
             {
-                uint32_t c[16];
+                uint32_t c[24];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { c[q] = s_cnt[q]; total += c[q]; }
+                for (int q = 0; q < 24; ++q) { c[q] = s_cnt[q]; total += c[q]; }
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
                     if (key[k] == 0xFFFFFFFFu) continue;
                     uint32_t base = 0;
 #pragma unroll
-                    for (int q = 0; q < 15; ++q) base += ((uint32_t)q < key[k]) ? c[q] : 0u;
+                    for (int q = 0; q < 23; ++q) base += ((uint32_t)q < key[k]) ? c[q] : 0u;
                     s_list[base + rank[k]] = (uint16_t)(k * WIDE_BLOCK + tid);
                 }
             }
@@ -491,11 +491,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
                 const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
                 const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
-                const bool wide4 = __ballot(has && (la > 64u || lb > 64u)) != 0ull;
+                const bool wide3 = __ballot(has && (la > 64u || lb > 64u)) != 0ull;
+                const bool wide4 = __ballot(has && (la > 96u || lb > 96u)) != 0ull;
                 bool done = false;
                 double res = 0.0;
-                if (!wide4)
+                if (!wide3)
                     wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                else if (!wide4)
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
                 else
                     wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
                 if (done) {

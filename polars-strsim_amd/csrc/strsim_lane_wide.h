@@ -1,4 +1,4 @@
-// strsim_lane_wide.h -- per-lane cores for strings of up to 32*W bytes (W = 2: 64, W = 4: 128), ASCII.
+// strsim_lane_wide.h -- per-lane cores for strings of up to 32*W bytes (W = 2: 64, W = 3: 96, W = 4: 128), ASCII.
 //
 // Same bit-sliced formulation as strsim_lane_core.h, with every mask W words wide.  The text is not
 // kept in registers: it is read one dword (4 bytes) at a time through `txt(g)` (an LDS column per lane
@@ -74,6 +74,12 @@ STRSIM_HD void shl1_one(uint32_t (&x)[2])
     asm("s_mov_b64 vcc, -1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
         : "+v"(x[0]), "+v"(x[1]) : : "vcc");
 }
+STRSIM_HD void shl1_one(uint32_t (&x)[3])
+{
+    asm("s_mov_b64 vcc, -1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : : "vcc");
+}
 STRSIM_HD void shl1_one(uint32_t (&x)[4])
 {
     asm("s_mov_b64 vcc, -1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
@@ -86,6 +92,12 @@ STRSIM_HD void shl1_ge(uint32_t (&x)[2], uint32_t a, uint32_t b)
 {
     asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
         : "+v"(x[0]), "+v"(x[1]) : "s"(a), "v"(b) : "vcc"); // (a: the column index, wave-uniform)
+}
+STRSIM_HD void shl1_ge(uint32_t (&x)[3], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_ge_u32_e32 vcc, %3, %4\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "s"(a), "v"(b) : "vcc");
 }
 STRSIM_HD void shl1_ge(uint32_t (&x)[4], uint32_t a, uint32_t b)
 {
@@ -111,6 +123,11 @@ STRSIM_HD void minus1_wide(const uint32_t (&x)[2], uint32_t (&d)[2])
 {
     asm("v_subrev_co_u32_e32 %0, vcc, 1, %2\n\tv_subbrev_co_u32_e32 %1, vcc, 0, %3, vcc"
         : "=&v"(d[0]), "=&v"(d[1]) : "v"(x[0]), "v"(x[1]) : "vcc");
+}
+STRSIM_HD void minus1_wide(const uint32_t (&x)[3], uint32_t (&d)[3])
+{
+    asm("v_subrev_co_u32_e32 %0, vcc, 1, %3\n\tv_subbrev_co_u32_e32 %1, vcc, 0, %4, vcc\n\tv_subbrev_co_u32_e32 %2, vcc, 0, %5, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]) : "vcc");
 }
 STRSIM_HD void minus1_wide(const uint32_t (&x)[4], uint32_t (&d)[4])
 {
@@ -141,6 +158,11 @@ STRSIM_HD void add_wide(const uint32_t (&x)[2], const uint32_t (&y)[2], uint32_t
     asm("v_add_co_u32_e32 %0, vcc, %2, %4\n\tv_addc_co_u32_e32 %1, vcc, %3, %5, vcc"
         : "=&v"(s[0]), "=&v"(s[1]) : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]) : "vcc");
 }
+STRSIM_HD void add_wide(const uint32_t (&x)[3], const uint32_t (&y)[3], uint32_t (&s)[3])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %3, %6\n\tv_addc_co_u32_e32 %1, vcc, %4, %7, vcc\n\tv_addc_co_u32_e32 %2, vcc, %5, %8, vcc"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2]) : "vcc");
+}
 STRSIM_HD void add_wide(const uint32_t (&x)[4], const uint32_t (&y)[4], uint32_t (&s)[4])
 {
     asm("v_add_co_u32_e32 %0, vcc, %4, %8\n\tv_addc_co_u32_e32 %1, vcc, %5, %9, vcc\n\t"
@@ -152,6 +174,11 @@ STRSIM_HD void shl1_zero(uint32_t (&x)[1]) { x[0] = x[0] + x[0]; }
 STRSIM_HD void shl1_zero(uint32_t (&x)[2])
 {
     asm("v_add_co_u32_e32 %0, vcc, %0, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(x[0]), "+v"(x[1]) : : "vcc");
+}
+STRSIM_HD void shl1_zero(uint32_t (&x)[3])
+{
+    asm("v_add_co_u32_e32 %0, vcc, %0, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\tv_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : : "vcc");
 }
 STRSIM_HD void shl1_zero(uint32_t (&x)[4])
 {

@@ -183,6 +183,7 @@ extern "C" double harness_lane_pair_wide(int measure, int W, const uint8_t *a, u
 {
     if (W == 1) return run_wide_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill);
     if (W == 2) return run_wide_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 3) return run_wide_m<3>(measure, a, la, b, lb, force_np, (uint8_t)fill);
     return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
 }
 

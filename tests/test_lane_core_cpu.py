@@ -124,7 +124,7 @@ def test_lane_core_length_boundaries(harness, measure):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
-@pytest.mark.parametrize("W", [1, 2, 4])
+@pytest.mark.parametrize("W", [1, 2, 3, 4])
 def test_wide_cores_random_bit_exact(harness, measure, W):
     rng = random.Random(1000 + W)
     for alphabet in (b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))):
@@ -143,7 +143,7 @@ def test_wide_cores_length_boundaries(harness, measure):
     lens = (1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128)
     for la in lens:
         for lb in lens:
-            W = 4 if max(la, lb) > 64 else 2
+            W = 4 if max(la, lb) > 96 else (3 if max(la, lb) > 64 else 2)
             a = bytes(rng.choice(b"abc") for _ in range(la))
             b = bytes(rng.choice(b"abc") for _ in range(lb))
             got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, la, b, lb, 0, ord("c"))
