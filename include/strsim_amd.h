@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010000u /* major<<16 | minor */
+#define STRSIM_ABI_VERSION 0x00010002u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
