@@ -529,6 +529,8 @@ struct LdsSym {
 };
 struct LdsSymEmit {
     uint16_t *col;
+    // (utf8_decode_lane emits every byte position, a value's index possibly several times, and a don't-care at index `count`:
+    // with 32 values that is index 32 -- dropped, like everything behind it: a longer string is not this kernel's anyway)
     __device__ __forceinline__ void operator()(uint32_t k, uint32_t cp) const { if (k < 32u) col[k * 64u] = (uint16_t)cp; }
 };
 

@@ -12,47 +12,74 @@
 namespace strsim {
 
 // ---------------------------------------------------------------------------------------------
-// `str::chars()` for one lane: walk the first len8 bytes of the 32*NW-byte window w[], call emit(k, cp) for the k-th
-// scalar value.  nd4 = number of dwords to walk (lane-uniform bound >= ceil(len8 / 4)).  Valid UTF-8 only.
-// Returns the number of scalar values; `big` is set when one exceeds 0xFFFF, `ovar`/`avar` accumulate OR / AND of
-// the emitted values (for the plane-count choice).
+// `str::chars()` for one lane: walk the first len8 bytes of the 32*NW-byte window w[] and hand the scalar values to `emit`.
+// nd4 = number of dwords to walk (lane-uniform bound >= ceil(len8 / 4)).  Valid UTF-8 only.  Returns the number of scalar
+// values; `big` is set when one exceeds 0xFFFF, `ovar`/`avar` accumulate OR / AND of the values (for the plane-count choice).
+//
+// Branch-free, four byte positions per trip (the per-byte state machine this replaces cost ~5 divergent branches per byte):
+// with the next two bytes of every position lined up beside it (two v_alignbyte), the value a position WOULD start is formed
+// for all four positions at once, byte lane by byte lane -- its low byte and its high byte separately, which is also how the
+// plane build wants the symbols:
+//     0xxxxxxx                      lo = b0                               hi = 0
+//     110xxxxx 10xxxxxx             lo = (b0 & 3) << 6 | (b1 & 0x3F)       hi = (b0 >> 2) & 7
+//     1110xxxx 10xxxxxx 10xxxxxx    lo = (b1 & 3) << 6 | (b2 & 0x3F)       hi = (b0 & 15) << 4 | (b1 >> 2) & 15
+// (a lead byte 1111xxxx starts a value beyond 0xFFFF: `big`).  EVERY position is then emitted at the running count of lead
+// bytes in front of it: a lead byte lands at its value's index, a continuation byte (or a byte behind the string) writes a
+// don't-care at the index of the value that follows and is overwritten by it -- emit(k, v) must accept any k (the callers
+// drop what is beyond their capacity) and the same k more than once, and the entry at index `count` may be left holding a
+// don't-care (so a caller with room for N values must drop index N, not wrap it onto index 0).
 // ---------------------------------------------------------------------------------------------
+STRSIM_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) // ({hi, lo} >> 8 * sh), sh = 1 .. 3
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * sh));
+#endif
+}
+STRSIM_HD uint32_t byte_masks(uint32_t bits01) { return (bits01 << 8) - bits01; } // bytes 0 / 1 -> 0x00 / 0xFF
+STRSIM_HD uint32_t fold_or8(uint32_t x) { x |= x >> 16; x |= x >> 8; return x & 0xFFu; }
+STRSIM_HD uint32_t fold_and8(uint32_t x) { x &= x >> 16; x &= x >> 8; return x & 0xFFu; }
+
 template <int NDW, class Emit>
 STRSIM_HD uint32_t utf8_decode_lane(const uint32_t (&w)[NDW], uint32_t len8, uint32_t nd4, const Emit &emit, bool &big,
                                     uint32_t &ovar, uint32_t &avar)
 {
-    uint32_t k = 0;       // scalar values emitted so far
-    uint32_t cp = 0;      // value being assembled
-    bool open = false;    // a value is being assembled
+    uint32_t k = 0;                               // lead bytes (= scalar values) so far
+    uint32_t o_lo = 0u, o_hi = 0u, a_lo = 0xFFFFFFFFu, a_hi = 0xFFFFFFFFu, four = 0u;
 #pragma unroll
     for (int d = 0; d < NDW; ++d) {
         if ((uint32_t)d >= nd4) break;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t p = 4u * (uint32_t)d + (uint32_t)q;
-            const uint32_t b = (w[d] >> (8 * q)) & 0xFFu;
-            if (p < len8) {
-                if ((b & 0xC0u) == 0x80u) {
-                    cp = (cp << 6) | (b & 0x3Fu);
-                } else {
-                    if (open) {
-                        emit(k, cp);
-                        big = big || cp > 0xFFFFu;
-                        ovar |= cp; avar &= cp;
-                        ++k;
-                    }
-                    open = true;
-                    cp = b < 0x80u ? b : (b < 0xE0u ? (b & 0x1Fu) : (b < 0xF0u ? (b & 0x0Fu) : (b & 0x07u)));
-                }
-            }
-        }
+        const uint32_t cur = w[d], nxt = d + 1 < NDW ? w[d + 1 < NDW ? d + 1 : d] : 0u;
+        const uint32_t w1 = align_bytes(nxt, cur, 1u), w2 = align_bytes(nxt, cur, 2u);
+        const uint32_t b7 = (cur >> 7) & 0x01010101u, b6 = (cur >> 6) & 0x01010101u, b5 = (cur >> 5) & 0x01010101u;
+        const uint32_t m7 = byte_masks(b7), m5 = byte_masks(b5);
+        // positions of this dword inside the string
+        const int32_t rem = (int32_t)len8 - 4 * d;
+        const uint32_t cut = rem >= 4 ? 0u : (rem <= 0 ? 4u : (uint32_t)(4 - rem));
+        const uint32_t vb = cut >= 4u ? 0u : (0x01010101u >> (8u * cut));
+        const uint32_t leadb = bitop3<0x8A>(b7, b6, vb); // (~b7 | b6) & vb: not a continuation byte, inside the string
+        const uint32_t ml = byte_masks(leadb);
+        const uint32_t lo2 = ((cur & 0x03030303u) << 6) | (w1 & 0x3F3F3F3Fu);
+        const uint32_t lo3 = ((w1 & 0x03030303u) << 6) | (w2 & 0x3F3F3F3Fu);
+        const uint32_t hi2 = (cur >> 2) & 0x07070707u;
+        const uint32_t hi3 = ((cur & 0x0F0F0F0Fu) << 4) | ((w1 >> 2) & 0x0F0F0F0Fu);
+        const uint32_t lo = bitop3<0xCA>(m7, bitop3<0xCA>(m5, lo3, lo2), cur);
+        const uint32_t hi = m7 & bitop3<0xCA>(m5, hi3, hi2);
+        four |= cur & (cur << 1) & (cur << 2) & (cur << 3) & (leadb << 7); // lead byte 1111xxxx
+        o_lo = bitop3<0xF8>(o_lo, lo, ml); o_hi = bitop3<0xF8>(o_hi, hi, ml); // o | (v & ml)
+        a_lo = bitop3<0xD0>(a_lo, lo, ml); a_hi = bitop3<0xD0>(a_hi, hi, ml); // a & (v | ~ml)
+        const uint32_t s01 = perm_b32(hi, lo, 0x05010400u); // [lo.b0, hi.b0, lo.b1, hi.b1]: positions 0 and 1 as 16-bit values
+        const uint32_t s23 = perm_b32(hi, lo, 0x07030602u);
+        emit(k, s01 & 0xFFFFu); k += leadb & 1u;
+        emit(k, s01 >> 16);     k += (leadb >> 8) & 1u;
+        emit(k, s23 & 0xFFFFu); k += (leadb >> 16) & 1u;
+        emit(k, s23 >> 16);     k += leadb >> 24;
     }
-    if (open) {
-        emit(k, cp);
-        big = big || cp > 0xFFFFu;
-        ovar |= cp; avar &= cp;
-        ++k;
-    }
+    big = big || four != 0u;
+    ovar |= fold_or8(o_lo) | (fold_or8(o_hi) << 8);
+    avar &= (fold_and8(a_lo) | (fold_and8(a_hi) << 8)) | 0xFFFF0000u;
+    if (k != 0u) avar &= 0x0000FFFFu; // (as the per-value AND of 16-bit values left it)
     return k;
 }
 
