@@ -861,19 +861,21 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
     // k on the copy stream) while the host packs slice k+2.  PCIe carries 41 B in and 8 B out per pair in the two directions at once, the host
     // touches every byte once (pack) -- per 2 M-row slice 1.45 ms of link against 1.3 ms of packing.  Slices ramp up from
     // RAMP_ROWS and down again at the end, so that neither the first pack nor the last slice's trip is exposed at full size.
-    // (cutting a 1 M-row call into four equal slices was tried in round 1: the four small packs cost 1.3 ms instead of
-    // 0.6 ms and the call got slower -- hence the floor)
+    // (in round 1 cutting a 1 M-row call into four slices lost -- four small packs cost 1.3 ms instead of 0.6 ms; with both columns
+    // in one job and a pool that spins between jobs it wins, so only calls up to SINGLE_ROWS stay in one piece)
     static const uint64_t RAMP_ROWS = env_rows("POLARS_STRSIM_RAMP_ROWS", 512u << 10);   // first slice (tuning knobs)
     static const uint64_t FULL_ROWS = env_rows("POLARS_STRSIM_SLICE_ROWS", SLICE_ROWS);   // steady-state slice
     static const uint64_t GROW_PCT = env_rows("POLARS_STRSIM_RAMP_GROW_PCT", 150);         // slice k+1 = slice k x this / 100
+    static const uint64_t SINGLE_ROWS = env_rows("POLARS_STRSIM_SINGLE_SLICE_ROWS", 300000); // calls up to here are not cut (1 M rows in four slices: 2.39 -> 2.06 ms)
     uint64_t prev_rows = 0;
     auto next_rows = [&](uint64_t r0) -> uint64_t {
         const uint64_t left = hi - r0;
-        if (direct_call || hi - lo <= (1u << 20)) return left;      // small calls: one slice
-        uint64_t want = prev_rows == 0 ? RAMP_ROWS : std::min<uint64_t>(FULL_ROWS, prev_rows * GROW_PCT / 100);
+        if (direct_call || hi - lo <= SINGLE_ROWS) return left;     // small calls: one slice
+        const uint64_t ramp = hi - lo <= (2u << 20) ? RAMP_ROWS / 2 : RAMP_ROWS; // a mid-size call starts (and stays) smaller
+        uint64_t want = prev_rows == 0 ? ramp : std::min<uint64_t>(FULL_ROWS, prev_rows * GROW_PCT / 100);
         want = std::min<uint64_t>(want, SLICE_ROWS);
-        if (left < 2 * want) want = std::max<uint64_t>(RAMP_ROWS, ((left / 2 + 65535) >> 16) << 16); // taper
-        if (left <= want + RAMP_ROWS / 2) want = left;              // no crumbs
+        if (left < 2 * want) want = std::max<uint64_t>(ramp, ((left / 2 + 65535) >> 16) << 16); // taper
+        if (left <= want + ramp / 2) want = left;                   // no crumbs
         prev_rows = want;
         return want;
     };
