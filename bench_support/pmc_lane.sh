@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the one-pair-per-lane kernel of one build/arm (GPU box): bash bench_support/pmc_lane.sh <tag> "<ENV=..>" [bench args]
-# prints the mean per launch of each counter for kernels named k_lane_p* (k_lane_pairs / k_lane_pipe)
+# prints the mean per launch of each counter for the one-pair-per-lane kernels (k_lane_pairs, k_lane_stage)
 TAG=$1; ARM="$2"; shift 2
 ROOT=$(pwd); export TMPDIR=/tmp
 ROWS=${ROWS:-20000000}
@@ -21,7 +21,7 @@ import csv,sys,collections
 acc=collections.defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if any(k in r["Kernel_Name"] for k in ("k_lane_pairs", "k_lane_pipe", "k_lane_stage")): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in ("k_lane_pairs", "k_lane_stage")): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 except Exception as e:
     print("  (no counters: %r)" % (e,))
 rows=float(sys.argv[2])
