@@ -197,6 +197,23 @@ static double run_sym_np(const uint16_t *ta, uint32_t la, const uint16_t *pb, ui
     return lane_sym_result<M, NP>(SymArr{ta}, la, la, SymArr{pb}, lb);
 }
 
+// utf8_decode_lane on its own: the scalar values of a string of n <= 128 bytes (garbage behind it in the window) -> out[0 .. 131],
+// returns their count; flags[0] = big, flags[1] = OR of the values, flags[2] = AND of the values (low 16 bits)
+extern "C" uint32_t harness_utf8_decode(const uint8_t *a, uint32_t n, int fill, uint16_t *out, uint32_t *flags)
+{
+    uint32_t w[32];
+    std::memset(w, fill, sizeof w);
+    std::memcpy(w, a, n);
+    struct Emit { uint16_t *s; void operator()(uint32_t k, uint32_t cp) const { if (k < 132) s[k] = (uint16_t)cp; } };
+    bool big = false;
+    uint32_t ov = 0, av = 0xFFFFFFFFu;
+    const uint32_t cnt = utf8_decode_lane<32>(w, n, (n + 3) / 4, Emit{out}, big, ov, av);
+    flags[0] = big ? 1u : 0u;
+    flags[1] = ov;
+    flags[2] = av & 0xFFFFu;
+    return cnt;
+}
+
 // returns -1.0 when the pair is not eligible (more than 32 scalar values, or one outside the BMP, or an empty side)
 extern "C" double harness_lane_pair_sym(int measure, const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, int force_np)
 {

@@ -39,6 +39,8 @@ def harness():
     L.harness_cores32.restype = C.c_int
     L.harness_cores32.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                   C.POINTER(C.c_uint32)]
+    L.harness_utf8_decode.restype = C.c_uint32
+    L.harness_utf8_decode.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]
     L.harness_check_planes.restype = C.c_int
     L.harness_check_planes.argtypes = [C.c_char_p]
     return L
@@ -297,3 +299,37 @@ def test_one_loop_cores(harness, np_, alphabet):
         assert out[0] == _edit_distance(a, b), (a, b, tmin, tmax)
         assert (out[1], out[2]) == _jaro_ints(a, b), (a, b, tmin, tmax, out[1], out[2])
         assert out[3] == _isect(a, b), (a, b, tmin, tmax)
+
+
+@pytest.mark.parametrize("fill", [0x00, 0x61, 0xAB, 0xCD, 0xE4, 0xF0])
+def test_utf8_decode_lane(harness, fill):
+    """utf8_decode_lane (branch-free, four byte positions per trip) = str::chars() for valid UTF-8 of up to 128 bytes: the
+    values in order, their count, OR / AND of the values, `big` iff one is beyond the BMP; whatever bytes follow the string in
+    the window (continuation bytes, lead bytes of every class) are not seen."""
+    rng = random.Random(900 + fill)
+    pools = ["abcxyz 09", "éüñß¢", "абвгдя", "αβγω", "日本語한", "\u0800\uffff\u07ff\u0080\u007f", "a𝄞😀"]
+    out = (C.c_uint16 * 132)()
+    flags = (C.c_uint32 * 3)()
+    for _ in range(4000):
+        pool = "".join(rng.sample(pools, rng.randint(1, 3)))
+        s = ""
+        while True:
+            c = rng.choice(pool)
+            if len((s + c).encode()) > rng.choice((8, 40, 128)) or len(s) >= 128:
+                break
+            s += c
+        b = s.encode()
+        for i in range(132):
+            out[i] = 0x5A5A
+        cnt = harness.harness_utf8_decode(b, len(b), fill, out, flags)
+        cps = [ord(ch) for ch in s]
+        assert cnt == len(cps), (s, cnt)
+        assert flags[0] == (1 if any(cp > 0xFFFF for cp in cps) else 0), s
+        if not flags[0]:
+            assert [out[i] for i in range(cnt)] == cps, s
+            if cps:
+                o = a = cps[0]
+                for cp in cps:
+                    o |= cp
+                    a &= cp
+                assert flags[1] & 0xFFFF == o and flags[2] == a, (s, hex(flags[1]), hex(flags[2]))
