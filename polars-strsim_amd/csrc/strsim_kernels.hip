@@ -282,8 +282,13 @@ k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int WIDE_BLOCK = 256;
 constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
-constexpr int WIDE_SPAN = 32;               // mask words (64-row chunks) per span
-constexpr int WIDE_ROWS = WIDE_SPAN * 64;   // 2048 rows
+#ifndef STRSIM_WIDE_SPAN
+#define STRSIM_WIDE_SPAN 64 // cfg3: 6.20 -> 5.89 ms against 32 (fuller rounds, longer hand-out queues); 128 does not fit LDS three times
+#endif
+constexpr int WIDE_SPAN = STRSIM_WIDE_SPAN;  // mask words (64-row chunks) per span of k_lane_wide
+constexpr int WIDE_ROWS = WIDE_SPAN * 64;    // 4096 rows
+constexpr int U8_SPAN = 32;                  // ... of k_lane_utf8 (its symbol columns take the LDS: a larger span costs a workgroup per CU)
+constexpr int U8_ROWS = U8_SPAN * 64;        // 2048 rows
 constexpr int WIDE_MAXW = 4;
 
 // NDW dwords of vals[start, start + 4*NDW); bytes outside [0, total) read as 0.  start may be negative.
@@ -555,35 +560,35 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                                                           unsigned long long *__restrict__ slowmask, uint32_t sps,
                                                           uint32_t *__restrict__ worklist, DevStatus *__restrict__ status)
 {
-    __shared__ unsigned long long s_mask[WIDE_SPAN];
+    __shared__ unsigned long long s_mask[U8_SPAN];
     __shared__ uint32_t s_cnt[8];
-    __shared__ uint16_t s_list[WIDE_ROWS];
+    __shared__ uint16_t s_list[U8_ROWS];
     __shared__ uint16_t s_symA[WIDE_WAVES][32][64];
     __shared__ uint16_t s_symB[WIDE_WAVES][32][64];
 
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
-    constexpr int RPT = WIDE_ROWS / WIDE_BLOCK;
+    constexpr int RPT = U8_ROWS / WIDE_BLOCK;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     __builtin_amdgcn_s_setprio(1);
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
-    const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
-    // sps spans per super (1 .. WIDE_BLOCK / WIDE_SPAN, chosen by the launcher so that a mid-size frame still makes
+    const uint64_t nspans = (nchunks + U8_SPAN - 1) / U8_SPAN;
+    // sps spans per super (1 .. WIDE_BLOCK / U8_SPAN, chosen by the launcher so that a mid-size frame still makes
     // enough workgroups to fill the chip)
     const uint64_t nsuper = (nspans + sps - 1) / sps;
-    const uint32_t super_words = sps * (uint32_t)WIDE_SPAN;
+    const uint32_t super_words = sps * (uint32_t)U8_SPAN;
 
     for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
       const uint64_t cw = sup * super_words + tid;
       const unsigned long long myword = (tid < super_words && cw < nchunks) ? slowmask[cw] : 0ull;
       if (!__syncthreads_or(myword != 0ull)) continue;
       for (uint64_t span = sup * sps; span < (sup + 1) * sps && span < nspans; ++span) {
-        const uint64_t c0 = span * WIDE_SPAN;
-        if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
+        const uint64_t c0 = span * U8_SPAN;
+        if (tid < (uint32_t)U8_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
         if (tid < 8u) s_cnt[tid] = 0u;
         __syncthreads();
-        const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
+        const bool any = __ballot(s_mask[lane & (U8_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
             uint32_t key[RPT], rank[RPT];
 #pragma unroll
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                 }
             }
             __syncthreads();
-            if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
+            if (tid < (uint32_t)U8_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
         }
         __syncthreads();
       }
@@ -1785,19 +1790,19 @@ __global__ __launch_bounds__(64) void k_huge_pairs(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// k_lane_wide / k_lane_utf8 geometry: spans (32 mask words) per super-span and workgroups.  A super is what one
+// k_lane_wide / k_lane_utf8 geometry: spans (WIDE_SPAN / U8_SPAN mask words) per super-span and workgroups.  A super is what one
 // workgroup tests for "anything to do" with a single barrier; full-size frames use the largest (8 spans), smaller
 // ones shrink it until there are about two supers per RESIDENT workgroup (a.wide_grid = 3 per CU).  The launch
 // itself may be much larger than what is resident (a.wide_grid_cap): workgroups that finish early are replaced by
 // fresh ones instead of waiting for the longest grid-stride loop (cfg3: 12.4 -> 10.3 ms).
-static void wide_geometry(const LaunchArgs &a, uint32_t &sps, unsigned &grid)
+static void wide_geometry(const LaunchArgs &a, int span, uint32_t &sps, unsigned &grid)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
-    const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
+    const uint64_t nspans = (nchunks + (uint64_t)span - 1) / (uint64_t)span;
     const uint64_t want = 2u * (uint64_t)a.wide_grid;
     uint64_t k = nspans / (want ? want : 1u);
     if (k < 1u) k = 1u;
-    if (k > (uint64_t)(WIDE_BLOCK / WIDE_SPAN)) k = WIDE_BLOCK / WIDE_SPAN;
+    if (k > (uint64_t)(WIDE_BLOCK / span)) k = WIDE_BLOCK / span;
     sps = (uint32_t)k;
     const uint64_t nsuper = (nspans + k - 1u) / k;
     grid = (unsigned)(nsuper < (uint64_t)a.wide_grid_cap ? nsuper : (uint64_t)a.wide_grid_cap);
@@ -1850,13 +1855,14 @@ static void launch_slow_t(const LaunchArgs &a)
                         : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 4u : (uint64_t)a.wave_grid;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
     {
-        uint32_t sps;
-        unsigned g3;
-        wide_geometry(a, sps, g3);
+        uint32_t sps, sps8;
+        unsigned g3, g8;
+        wide_geometry(a, WIDE_SPAN, sps, g3);
+        wide_geometry(a, U8_SPAN, sps8, g8);
         hipLaunchKernelGGL((k_lane_wide<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, sps);
-        hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, sps, a.worklist, a.status);
+        hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g8), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                           a.offB, a.valB, a.rowsB, a.out, a.n, a.slowmask, sps8, a.worklist, a.status);
     }
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, a.out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
@@ -1895,17 +1901,18 @@ template <int M>
 static void launch_slow_kernels(const LaunchArgs &a, double *out)
 {
     const uint64_t nchunks = (a.n + 63u) >> 6;
-    uint32_t sps;
-    unsigned g3;
-    wide_geometry(a, sps, g3);
+    uint32_t sps, sps8;
+    unsigned g3, g8;
+    wide_geometry(a, WIDE_SPAN, sps, g3);
+    wide_geometry(a, U8_SPAN, sps8, g8);
     // waves per CU: Levenshtein by its 8 KB table; Jaro by its 12.4 KB of LDS (12); Jaccard / Dice 16 (a.wave_grid)
     const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
                         : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 4u : (uint64_t)a.wave_grid;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
     hipLaunchKernelGGL((k_lane_wide<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask, sps);
-    hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g3), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
-                       a.valB, a.rowsB, out, a.n, a.slowmask, sps, a.worklist, a.status);
+    hipLaunchKernelGGL((k_lane_utf8<M>), dim3(g8), dim3(WIDE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
+                       a.valB, a.rowsB, out, a.n, a.slowmask, sps8, a.worklist, a.status);
     hipLaunchKernelGGL((k_wave_pairs<M>), dim3((unsigned)g2), dim3(64), 0, a.stream, a.offA, a.valA, a.rowsA, a.offB,
                        a.valB, a.rowsB, out, a.n, a.slowmask, a.worklist, a.status, a.lev_ws);
 }
