@@ -86,8 +86,21 @@ def cpu_baseline(measure, cfg, rows_total):
                       f"(split_offsets partition){quota_note}"}, (n, out)
 
 
-def plugin_e2e(measure, cfg, rows):
-    """PCIe-inclusive rate through _polars_plugin_<measure> (host Arrow string views in, host f64 out) on a prefix."""
+def plugin_e2e(measure, cfg, rows, name=None):
+    """PCIe-inclusive rate through _polars_plugin_<measure> (host Arrow string views in, host f64 out) on a prefix.
+    Measured in a CHILD process (this file, --e2e-child): what bounds such a call is host CPU time against the container's
+    quota, and this process still carries torch's and the generator's thread pools (in-process the same call measured
+    30-40 % slower than in a fresh interpreter)."""
+    if name is not None:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child", name, measure, str(rows)],
+                               capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                return json.loads(line[-1])
+        except Exception:
+            pass  # fall through: measure here
     import numpy as np
     import pyarrow as pa
     from bench_support import workload as W
@@ -344,7 +357,7 @@ def main():
             res["gcups"] = cells * len(measures) * a.steps / dt / 1e9  # DP cells per second (compute-bound workloads)
         if not a.no_e2e and world == 1 and len(measures) == 1:
             try:
-                res["end_to_end_plugin_abi"] = plugin_e2e(measures[0], cfg, rows)
+                res["end_to_end_plugin_abi"] = plugin_e2e(measures[0], cfg, rows, a.config)
             except Exception as e:
                 res["end_to_end_plugin_abi"] = {"value": None, "note": "failed: %r" % (e,)}
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
@@ -364,4 +377,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 5 and sys.argv[1] == "--e2e-child":  # bench.py --e2e-child <config> <measure> <rows>
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "polars-strsim_amd"))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from bench_support import workload as _W
+        print(json.dumps(plugin_e2e(sys.argv[3], _W.CONFIGS[sys.argv[2]], int(sys.argv[4]))), flush=True)
+    else:
+        main()
