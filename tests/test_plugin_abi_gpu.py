@@ -214,3 +214,26 @@ def test_large_call_with_and_without_pinned_result_and_length_bytes(H, monkeypat
                 check(got[lo:lo + 10_000], expect("levenshtein", A[lo:lo + 10_000], B[lo:lo + 10_000]))
         else:
             assert got.equals(ref), (pinned, lens)
+
+
+def test_large_call_over_two_pipelines_lands_in_one_pinned_column(H, monkeypatch):
+    """4.6 M rows: enough for two device pipelines at the default rows-per-device threshold, and a result column that comes
+    from the pinned pool -- both pipelines' copy engines write their halves of it directly.  Equal, bit for bit, to the
+    one-pipeline call (whose parity with the oracle the other tests establish)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_support import workload as W
+    n = 4_600_000
+    _, _, law, lo, hi, seed = W.CONFIGS["cfg2"]
+    oa, va, ob, vb = W.host_columns(seed, law, lo, hi, 0, n)
+    mk = lambda o, v: pa.StringArray.from_buffers(n, pa.py_buffer(o.astype(np.int32)), pa.py_buffer(v)).cast(pa.string_view())
+    a, b = mk(oa, va), mk(ob, vb)
+    for m in ("levenshtein", "jaro_winkler"):
+        monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
+        one = H.call_plugin(m, a, b)
+        monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0,0")
+        two = H.call_plugin(m, a, b)
+        assert two.equals(one), m
+    monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
+    H.call_plugin("levenshtein", a[:1000], b[:1000])  # (this thread's context goes back to one device)
