@@ -156,7 +156,9 @@ STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *len
 /* For a caller that keeps several calls in flight on the context's stream and learns of their completion by its own means
  * (an event recorded on strsim_ctx_stream() behind each call): retire the OLDEST pending call only -- what
  * strsim_ctx_synchronize() does for all of them, without waiting for the younger ones.  The caller guarantees that the
- * oldest call's kernels have completed.  If that call held strings longer than STRSIM_WAVE_PATH_MAX_BYTES, their second
+ * oldest call's kernels have completed; the library checks it (the call's status block carries a ticket the device writes
+ * last) and returns STRSIM_ERR_ARG, leaving the call pending, when they have not -- an event recorded on any OTHER stream
+ * than strsim_ctx_stream() proves nothing about this context's kernels.  If that call held strings longer than STRSIM_WAVE_PATH_MAX_BYTES, their second
  * pass is launched and waited for here (strsim_ctx_last_long_rows() tells).  Reference counterpart: none -- the reference's
  * rayon loop (strsim.rs:72-100) has no device queue; this is what lets the plugin overlap H2D of slice k+1, the kernels of
  * slice k and the D2H of slice k-1. */

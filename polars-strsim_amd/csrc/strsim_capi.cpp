@@ -72,6 +72,8 @@ struct strsim_ctx {
     size_t pin_cap = 0;
     hipEvent_t ev[RING][3] = {};
     bool slot_pending[RING] = {};
+    uint32_t slot_ticket[RING] = {}; // what the device writes into status_host[slot].ticket when the call's status block is out
+    uint32_t ticket_seq = 0;
     bool slot_timed[RING] = {};
     LaunchArgs slot_args[RING] = {}; // what each pending call was launched with (for the long-string pass)
     int slot_measure[RING] = {};     // STRSIM_NUM_MEASURES = the fused all-measures call
@@ -147,10 +149,24 @@ static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
 
 // Retire one pending slot whose kernels have completed: timing, counters, the long-string pass.  A slot is retired whatever
 // fails on the way (a slot left pending would be re-run by a later synchronize with buffers its caller may have freed).
+// Has the device published the status block of the call in slot s?  (The ticket is the last word the publisher writes, with
+// release semantics at system scope; the acquire fence pairs with it.)
+static bool ctx_slot_published(const strsim_ctx *c, int s)
+{
+    const uint32_t seen = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].ticket);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return seen == c->slot_ticket[s];
+}
+
 static int ctx_retire_slot(strsim_ctx *c, int s)
 {
     int rc = STRSIM_OK;
     c->slot_pending[s] = false;
+    if (!ctx_slot_published(c, s)) { // (cannot happen behind a stream synchronise; strsim_ctx_retire_oldest checks before it gets here)
+        c->slot_timed[s] = false;
+        set_error("internal: the status block of a completed call was not published (slot %d)", s);
+        return STRSIM_ERR_INTERNAL;
+    }
     if (c->slot_timed[s]) {
         c->slot_timed[s] = false;
         float a = 0, b = 0;
@@ -350,6 +366,9 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long) + nchunks * sizeof(uint32_t));
     if (rc) return rc;
     // (the status block of the slot is cleared by the first kernel of the call, k_lane_pairs)
+    if (++c->ticket_seq == 0u) c->ticket_seq = 1u;
+    c->slot_ticket[slot] = c->ticket_seq;
+    c->status_host[slot].ticket = 0u; // (the slot is not pending: nothing on the device writes this block now)
 
     LaunchArgs la;
     la.offA = a_off; la.valA = a_val; la.rowsA = a_rows;
@@ -413,7 +432,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         c->slot_args[slot] = la;
         c->slot_measure[slot] = measure;
         for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = nullptr;
-        HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->stream));
+        HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->slot_ticket[slot], c->stream));
         c->slot_pending[slot] = true;
         c->head = (slot + 1) % strsim_ctx::RING;
         return STRSIM_OK;
@@ -424,7 +443,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     c->slot_args[slot] = la;
     c->slot_measure[slot] = measure;
     for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = all ? outs[q] : nullptr;
-    HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->stream));
+    HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->slot_ticket[slot], c->stream));
     c->slot_pending[slot] = true;
     c->head = (slot + 1) % strsim_ctx::RING;
     return STRSIM_OK;
@@ -479,7 +498,15 @@ int strsim_ctx_retire_oldest(strsim_ctx_t *c)
     c->last_long_rows = 0;
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
-        if (c->slot_pending[s]) return ctx_retire_slot(c, s);
+        if (!c->slot_pending[s]) continue;
+        if (!ctx_slot_published(c, s)) {
+            // the caller's promise does not hold (e.g. its event was recorded on another stream than strsim_ctx_stream()):
+            // say so instead of reading a status block the device has not written; the call stays pending
+            set_error("strsim_ctx_retire_oldest: the oldest call has not completed (wait on an event recorded on "
+                      "strsim_ctx_stream() behind it, or call strsim_ctx_synchronize())");
+            return STRSIM_ERR_ARG;
+        }
+        return ctx_retire_slot(c, s);
     }
     return STRSIM_OK; // nothing pending (e.g. a small call that completed inside strsim_pairs_device_small)
 }

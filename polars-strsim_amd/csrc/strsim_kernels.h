@@ -37,7 +37,9 @@ struct DevStatus {
     unsigned int list_count[5]; // k_lane_utf8: chunks of 64 rows that still hold unfinished rows ...
     unsigned int list_rows[5];  // ... and how many rows that is
     unsigned int next_entry[5]; // k_wave_pairs: work-list entries handed out beyond the first static round
-    unsigned int pad1[13];
+    unsigned int pad1[12];
+    unsigned int ticket;    // host-mapped copy only: the call's ticket, written LAST (release, system scope) by whoever publishes
+                            // the block -- strsim_ctx_retire_oldest() refuses a slot whose ticket has not arrived
 };
 static_assert(sizeof(DevStatus) == 128, "DevStatus is 128 bytes");
 
@@ -72,6 +74,6 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
 // Second pass for rows with a string longer than WAVE_CAP bytes: `grid` waves, each with HUGE_WS_WORDS(cap) words of `ws`.
 hipError_t launch_huge(int measure, const LaunchArgs &a, uint32_t *ws, uint32_t cap, int grid);
 // copies one DevStatus to host-mapped pinned memory from the device side (no copy-engine hand-over)
-hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, hipStream_t stream);
+hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, uint32_t ticket, hipStream_t stream);
 
 } // namespace strsim

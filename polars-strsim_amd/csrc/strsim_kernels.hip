@@ -25,6 +25,7 @@
 // No MFMA anywhere: this is integer/byte work whose roofline is HBM bytes.
 // Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <type_traits>
 
@@ -2001,17 +2002,20 @@ hipError_t launch_pairs(int measure, const LaunchArgs &a)
 
 // The call's status block, copied to pinned host memory by a one-wave kernel: an SDMA/blit copy behind the last kernel costs
 // a queue hand-over of 10-16 us per call, this costs ~2 us (visible to the host once the stream has been synchronised).
-__global__ void k_publish_status(const DevStatus *__restrict__ src, DevStatus *__restrict__ dst)
+__global__ void k_publish_status(const DevStatus *__restrict__ src, DevStatus *__restrict__ dst, uint32_t ticket)
 {
     const unsigned *s = reinterpret_cast<const unsigned *>(src);
     unsigned *d = reinterpret_cast<unsigned *>(dst);
-    if (threadIdx.x < sizeof(DevStatus) / 4) __builtin_nontemporal_store(s[threadIdx.x], d + threadIdx.x);
+    constexpr unsigned TICKET_WORD = offsetof(DevStatus, ticket) / 4;
+    if (threadIdx.x < sizeof(DevStatus) / 4 && threadIdx.x != TICKET_WORD) __builtin_nontemporal_store(s[threadIdx.x], d + threadIdx.x);
     __threadfence_system();
+    // the ticket goes last: a host that sees it sees the block (one wave: the stores above were issued before this one)
+    if (threadIdx.x == 0u) __hip_atomic_store(&dst->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, hipStream_t stream)
+hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, uint32_t ticket, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, stream, src, dst_mapped);
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, stream, src, dst_mapped, ticket);
     return hipGetLastError();
 }
 

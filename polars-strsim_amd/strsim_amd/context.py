@@ -22,11 +22,16 @@ class Context:
     """One GPU + one HIP stream + workspace (include/strsim_amd.h: strsim_ctx_t).  One per thread."""
 
     def __init__(self, device=0, stream=None):
-        """`stream`: an int hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or None / 0 for an own non-blocking
-        stream.  Note that torch's default stream has handle 0: pass an explicit torch stream when torch-side
-        stream waits / events must order against this context's kernels."""
+        """`stream`: an int hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or None for an own non-blocking stream.
+        Handle 0 -- torch's DEFAULT stream, `torch.cuda.current_stream().cuda_stream` outside a `torch.cuda.stream(s)`
+        block -- is refused: the C ABI reads NULL as "create your own stream", so the context would silently run on a
+        stream that torch-side events and copies are not ordered against.  Pass a real torch stream and do the torch-side
+        work (event.record(s), .cpu()) under `torch.cuda.stream(s)`, or pass None and use ctx.synchronize()."""
+        if stream is not None and int(stream) == 0:
+            raise ValueError("stream handle 0 is the default stream: pass None for an own stream, or a torch.cuda.Stream()'s "
+                             "cuda_stream (and run the torch-side work under torch.cuda.stream(s))")
         self._h = C.c_void_p()
-        check(lib().strsim_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        check(lib().strsim_ctx_create(int(device), C.c_void_p(int(stream)) if stream is not None else None, C.byref(self._h)))
         self.device = int(device)
 
     def close(self):

@@ -22,7 +22,25 @@ def _have_gpu():
         return False
 
 
+# The driver runs `pytest -x`: the first failure hides everything collected behind it.  So the drop-in boundary runs first
+# (C-ABI symbols, then the whole Polars-plugin ABI on the GPU, then the thin-ABI parity suite), the cheap suites next, and
+# the minutes-long full-size / fuzz files last -- whatever the alphabet says.
+_FILE_ORDER = ["test_abi_symbols.py", "test_plugin_abi_gpu.py", "test_plugin_configs_gpu.py", "test_hip_runtime_sharing.py",
+               "test_gpu_parity.py", "test_gpu_multirank_smoke.py", "test_packaging.py", "test_installed_wheel_gpu.py"]
+_FILE_LAST = ["test_gpu_hypothesis.py", "test_gpu_fuzz.py", "test_gpu_fullsize.py"]
+
+
+def _file_rank(item):
+    name = os.path.basename(str(item.fspath))
+    if name in _FILE_ORDER:
+        return _FILE_ORDER.index(name)
+    if name in _FILE_LAST:
+        return 1000 + _FILE_LAST.index(name)
+    return 500
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)  # (stable: the order inside a file is kept)
     # `-m gpu` on a box without a GPU must fail loudly, not skip; plain runs skip gpu tests without a GPU.
     if config.getoption("-m") and "gpu" in config.getoption("-m") and "not gpu" not in config.getoption("-m"):
         return

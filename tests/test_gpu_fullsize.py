@@ -25,7 +25,8 @@ def frame():
     _, _, law, lo, hi, seed = W.CONFIGS["cfg2"]
     dev = torch.device("cuda", 0)
     offA, valA, offB, valB, ba, bb = W.device_columns(seed, law, lo, hi, 0, ROWS, dev)
-    ctx = S.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()  # the generator's kernels ran on torch's stream; the context owns its stream (run() waits for it)
+    ctx = S.Context(0)
     yield dict(W=W, S=S, ctx=ctx, cols=(offA, valA, offB, valB), cfg=(seed, law, lo, hi), torch=torch)
     ctx.close()
 
@@ -131,7 +132,8 @@ def test_config_frame_full_size(name, rows, win, nwin):
     import strsim_amd as S
     rows = max(int(rows * SCALE), 4 * win)
     measure, cfg, parts = _device_frame(name, rows)
-    with S.Context(0, stream=t.cuda.current_stream().cuda_stream) as ctx:
+    t.cuda.synchronize()  # the frame is complete; the context's own stream is waited for inside run()
+    with S.Context(0) as ctx:
         def run(swap=False, same=False):
             out = t.empty(rows, dtype=t.float64, device="cuda")
             for r0, r1, oa, va, ob, vb in parts:
@@ -160,7 +162,8 @@ def test_cfg4_fused_five_outputs_full_size():
     import strsim_amd as S
     rows = max(int(200_000_000 * SCALE), 200_000)
     _, cfg, parts = _device_frame("cfg4", rows)
-    with S.Context(0, stream=t.cuda.current_stream().cuda_stream) as ctx:
+    t.cuda.synchronize()
+    with S.Context(0) as ctx:
         outs = [t.empty(rows, dtype=t.float64, device="cuda") for _ in S.MEASURES]
         for r0, r1, oa, va, ob, vb in parts:
             ctx.pairs_device_all(oa, va, ob, vb, outs=[o[r0:r1] for o in outs])

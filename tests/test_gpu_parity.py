@@ -317,7 +317,8 @@ def test_fused_all_measures_equals_single_measure_kernels(S):
     t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
     pad = np.zeros(64, dtype=np.uint8)
     cols = (t(ao, np.int32), t(np.concatenate([av, pad]), np.uint8), t(bo, np.int32), t(np.concatenate([bv, pad]), np.uint8))
-    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+    torch.cuda.synchronize()  # the uploads are complete; the context runs on its own stream and is waited for below
+    with S.Context(0) as ctx:
         outs = ctx.pairs_device_all(*cols)
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -370,7 +371,7 @@ def test_transport_codec_round_trip(S, measure):
     dev = torch.device("cuda", 0)
     t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
     pad = np.zeros(64, dtype=np.uint8)
-    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+    with S.Context(0) as ctx:  # its own stream: every hand-over to torch below goes through ctx.synchronize() / torch.cuda.synchronize()
         vals = ctx.pairs_device(measure, t(ao, np.int32), t(np.concatenate([av, pad]), np.uint8), t(bo, np.int32),
                                 t(np.concatenate([bv, pad]), np.uint8))
         ctx.synchronize()
@@ -415,8 +416,7 @@ def test_transport_codec_round_trip(S, measure):
 
 
 def test_transport_codec_rejects_oversized_tables(S):
-    import torch
-    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+    with S.Context(0) as ctx:
         with pytest.raises(S.StrsimError, match="do not fit 16-bit"):
             S.Codec(ctx, "jaro_winkler", 128)
         c = S.Codec(ctx, "levenshtein", 128)
@@ -438,10 +438,9 @@ def test_offsets_from_lengths(S, ctx, rows):
     assert np.array_equal(off.cpu().numpy().view(np.uint32), exp)
 
 
-def test_calls_in_flight_are_retired_one_at_a_time(S):
-    """strsim_ctx_retire_oldest: three calls enqueued back to back, each retired behind an event of the caller's own."""
+def _retire_frame(S, rows=30_000):
     import torch
-    A, B = gen.pairs(77, 30_000, gen.ASCII_LOWER, 0, 40)
+    A, B = gen.pairs(77, rows, gen.ASCII_LOWER, 0, 40)
     exp = O.batch_strings("levenshtein", A, B, 8)
     oa, va = S.pack_strings(A)
     ob, vb = S.pack_strings(B)
@@ -449,16 +448,54 @@ def test_calls_in_flight_are_retired_one_at_a_time(S):
     t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
     pad = np.zeros(64, dtype=np.uint8)
     args = (t(oa, np.int32), t(np.concatenate([va, pad]), np.uint8), t(ob, np.int32), t(np.concatenate([vb, pad]), np.uint8))
-    with S.Context(0, stream=torch.cuda.current_stream().cuda_stream) as ctx:
+    torch.cuda.synchronize()
+    return args, exp
+
+
+def test_calls_in_flight_are_retired_one_at_a_time(S):
+    """strsim_ctx_retire_oldest: three calls enqueued back to back, each retired behind an event of the caller's own --
+    recorded on the CONTEXT'S stream (a real torch stream handed to the context; everything torch does here runs on it)."""
+    import torch
+    args, exp = _retire_frame(S)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), S.Context(0, stream=s.cuda_stream) as ctx:
+        assert ctx.stream == s.cuda_stream
         outs, evs = [], []
         for _ in range(3):
             outs.append(ctx.pairs_device("levenshtein", *args))
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(s)
             evs.append(ev)
         for k in range(3):
             evs[k].synchronize()
             ctx.retire_oldest()
-            got = outs[k].cpu().numpy()
+            got = outs[k].cpu().numpy()  # (a copy on s, the current stream)
             assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), k
         ctx.synchronize()  # nothing left to retire
+    torch.cuda.synchronize()
+
+
+def test_retire_oldest_refuses_a_call_that_has_not_completed(S):
+    """The caller's promise is checked: with the stream held up behind the call's kernels' predecessor, retire_oldest()
+    returns STRSIM_ERR_ARG and leaves the call pending; once the stream has drained the same call retires and is right."""
+    import torch
+    args, exp = _retire_frame(S, 5_000)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), S.Context(0, stream=s.cuda_stream) as ctx:
+        torch.cuda._sleep(400_000_000)  # ~0.2 s of GPU spinning on s, in front of the call
+        out = ctx.pairs_device("levenshtein", *args)
+        with pytest.raises(S.StrsimError, match="has not completed"):
+            ctx.retire_oldest()
+        s.synchronize()
+        ctx.retire_oldest()       # now it has
+        ctx.retire_oldest()       # and nothing is pending: a no-op
+        got = out.cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+        ctx.synchronize()
+    torch.cuda.synchronize()
+
+
+def test_default_stream_handle_is_refused(S):
+    """Handle 0 would silently become an own stream inside the C ABI (NULL = create one): the Python layer says so instead."""
+    with pytest.raises(ValueError, match="default stream"):
+        S.Context(0, stream=0)

@@ -2,6 +2,7 @@
 puts libpolars_strsim_amd.so INSIDE the polars_strsim package directory, where Polars scans for the plugin library
 (reference polars_strsim/__init__.py:11-16 passes plugin_path = the package directory; reference pyproject.toml:1-34)."""
 import os
+import shutil
 import subprocess
 import sys
 import zipfile
@@ -13,6 +14,8 @@ def test_wheel_carries_the_plugin_library(tmp_path):
     src = os.path.join(ROOT, "polars-strsim_amd")
     r = subprocess.run([sys.executable, "-m", "pip", "wheel", src, "--no-build-isolation", "--no-deps", "-w", str(tmp_path)],
                        capture_output=True, text=True, timeout=1200)
+    for litter in ("build", "polars_strsim_amd.egg-info"):  # pip builds in the source tree: leave it as it was
+        shutil.rmtree(os.path.join(src, litter), ignore_errors=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     wheels = [f for f in os.listdir(tmp_path) if f.endswith(".whl")]
     assert len(wheels) == 1 and wheels[0].startswith("polars_strsim_amd-0.2.3")
