@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "strsim_lane_core.h"
+#include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
 #include "strsim_lane_sym.h"
 #include "strsim_kernels.h"
@@ -1837,7 +1838,9 @@ static void launch_lane_t(const LaunchArgs &a)
     } else if (a.stage_grid > 0) {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
-        const uint64_t gs = nsb < (uint64_t)a.stage_grid ? nsb : (uint64_t)a.stage_grid;
+        // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; a measure that runs fewer gets its share)
+        const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
+        const uint64_t gs = nsb < res ? nsb : res;
         hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
     } else {
@@ -1932,7 +1935,7 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     if (a.stage_grid > 0) {
         // one staged pass, five outputs (strsim_lane_stage.h, MEASURE = ALL_MEASURES)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
-        const uint64_t cap = (uint64_t)a.stage_grid * 4u / 5u; // 4 resident workgroups per CU
+        const uint64_t cap = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<ALL_MEASURES>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU; // resident workgroups
         const uint64_t gs = nsb < cap ? nsb : cap;
         hipLaunchKernelGGL(k_lane_stage_all, dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA,
                            a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);

@@ -31,7 +31,10 @@
 #define STRSIM_STAGE_ROWS 512
 #endif
 #ifndef STRSIM_STAGE_CAP
-#define STRSIM_STAGE_CAP 10240 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB)
+#define STRSIM_STAGE_CAP 9216 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB; a block that does not fit is cut)
+#endif
+#ifndef STRSIM_STAGE_CAP_LUT
+#define STRSIM_STAGE_CAP_LUT 8960 // the same for the instantiations with match-mask tables (40 KB of LDS: four workgroups per CU)
 #endif
 #ifndef STRSIM_STAGE_WAVES_PER_EU
 #define STRSIM_STAGE_WAVES_PER_EU 5
@@ -40,6 +43,9 @@
 #define STRSIM_STAGE_BUCKET_SHIFT 1
 #endif
 
+#ifndef STRSIM_STAGE_LUT
+#define STRSIM_STAGE_LUT 0x26 // bit m set: measure m (bit 5: the five-output pass) takes its match masks from per-lane LDS tables
+#endif                       //   (strsim_lane_lut.h) instead of bit fills.  Default: Jaro, Jaro-Winkler, the five-output pass.
 #ifndef STRSIM_STAGE_PRIO
 #define STRSIM_STAGE_PRIO 1
 #endif
@@ -75,13 +81,22 @@ constexpr int STAGE_ROWS = STRSIM_STAGE_ROWS;         // rows per block
 constexpr int STAGE_RPT = STAGE_ROWS / STAGE_BLOCK;   // rows per thread in the coalesced phases
 constexpr int STAGE_NR = STAGE_ROWS / 64;             // rounds per block
 constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and block
-constexpr int STAGE_CAP = STRSIM_STAGE_CAP;           // staged bytes per column
-constexpr int STAGE_COL = STAGE_CAP + 96;             // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
-constexpr int STAGE_DMA_ITERS = (STAGE_CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
+// Which instantiations use the LDS match-mask tables.  The tables cost 12 KB of LDS per workgroup (4 workgroups per CU
+// instead of 5) and pay where the kernel runs at 4 waves per SIMD or fewer anyway (Jaro's two passes; the five-output pass):
+// Jaro 41 -> 45.6 G pairs/s on cfg2's lengths.  Levenshtein, Jaccard and Dice are issue-bound at 5 workgroups per CU and
+// latency-bound at 4: 28 % fewer vector instructions bought nothing there.
+template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_LUT >> MEASURE) & 1) != 0; } // (5: five outputs)
+
+// staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
+template <int MEASURE> struct StageGeom {
+    static constexpr int CAP = stage_uses_lut<MEASURE>() ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP;
+    static constexpr int COL = CAP + 96;              // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
+    static constexpr int DMA_ITERS = (CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
+    static_assert(CAP % 16 == 0 && 2 * COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
+};
 constexpr int STAGE_BSH = STRSIM_STAGE_BUCKET_SHIFT;  // buckets of 2^BSH column counts
 constexpr int STAGE_NBK = (32 >> STAGE_BSH) + 1;      // + one for the rows this kernel leaves to the later ones
 static_assert(STAGE_RPT >= 1 && STAGE_RPT <= 4 && STAGE_RPW >= 1, "STAGE_ROWS is 256, 512 or 1024");
-static_assert(STAGE_CAP % 16 == 0 && 2 * STAGE_COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
 static_assert(STAGE_NBK <= 32, "the bucket scan runs on 32 lanes");
 
 // LDS byte address of a __shared__ object (what M0 / a DS instruction's address operand hold)
@@ -166,18 +181,20 @@ __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
 }
 
 // Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
-template <int NP>
-__device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
-                                                   uint32_t tmin, uint32_t tmax)
+template <int NP, bool USE_LUT>
+__device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
+                                                   uint32_t lb, uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
+    EqLut t = lut;
+    if (USE_LUT) lut_build<NP>(t, P, 0xFFFFFFFFu);
 #if STRSIM_STAGE_PRIO_PLANES
     __builtin_amdgcn_s_setprio(0);
 #endif
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
-    const uint32_t dist = lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    const uint32_t dist = USE_LUT ? lev_myers32_lut<NP>(t, wa, la1, tmin, tmax, P, lb1) : lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
     uint32_t code = dist * (uint32_t)QTAB_N + (la1 > lb1 ? la1 : lb1);
     // both empty: 1.0 = 1 - 0/1; one side empty: 0.0 = 1 - 1/1   (strsim.rs:128, :160)
     if (!live) code = (la == 0u && lb == 0u) ? 1u : (uint32_t)QTAB_N + 1u;
@@ -188,16 +205,22 @@ __device__ __forceinline__ uint32_t stage_lev_code(const uint32_t (&wa)[8], uint
 // into 64 bits: dist | m << 6 | t << 12 | I << 18 | common prefix << 24 | la << 27 | lb << 33 (all-ones is never produced).
 // Jaro's matching serves Jaro and Jaro-Winkler, the multiset intersection Jaccard and Dice; no role swap (Jaro walks a, so
 // every measure does).  The epilogues run in the store phase (stage_all_epilogues), once per row, on coalesced lanes.
-template <int NP>
-__device__ __forceinline__ unsigned long long stage_all_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
-                                                             uint32_t lb, uint32_t tmin, uint32_t tmax)
+template <int NP, bool USE_LUT>
+__device__ __forceinline__ unsigned long long stage_all_ints(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la,
+                                                             const uint32_t (&wb)[8], uint32_t lb, uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
     uint32_t dist, m, t, isect; // one column loop, one match mask per column for the three cores (lane_cores32)
-    lane_cores32<NP, true, true, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+    if (USE_LUT) {
+        EqLut tb = lut;
+        lut_build<NP>(tb, P, 0xFFFFFFFFu);
+        lane_cores32_lut<NP, true, true, true>(tb, wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+    } else {
+        lane_cores32<NP, true, true, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+    }
     const uint32_t pre = common_prefix4(wa[0], la1, wb[0], lb1);
     const uint32_t lo = dist | (m << 6) | (t << 12) | (isect << 18) | (pre << 24) | (la << 27); // la: 5 of its 6 bits fit here
     return (unsigned long long)lo | ((unsigned long long)(la >> 5) << 32) | ((unsigned long long)lb << 33);
@@ -227,21 +250,25 @@ __device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, doubl
 
 // One of the other four measures as 32 bits of integers: Jaro / Jaro-Winkler: m | t << 6 | la << 12 | lb << 18 | common
 // prefix << 24; Jaccard / Dice: I | la << 6 | lb << 12 (all-ones is never produced).  text = a, pattern = b.
-template <int MEASURE, int NP>
-__device__ __forceinline__ uint32_t stage_ints(const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8], uint32_t lb,
-                                               uint32_t tmin, uint32_t tmax)
+template <int MEASURE, int NP, bool USE_LUT>
+__device__ __forceinline__ uint32_t stage_ints(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
+                                               uint32_t lb, uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
     uint32_t dist, m, t, isect;
+    EqLut tb = lut;
+    if (USE_LUT) lut_build<NP>(tb, P, 0xFFFFFFFFu);
     if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
-        lane_cores32<NP, false, true, false>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+        if (USE_LUT) lane_cores32_lut<NP, false, true, false>(tb, wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+        else lane_cores32<NP, false, true, false>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
         const uint32_t pre = MEASURE == JARO_WINKLER ? common_prefix4(wa[0], la1, wb[0], lb1) : 0u;
         return m | (t << 6) | (la << 12) | (lb << 18) | (pre << 24);
     }
-    lane_cores32<NP, false, false, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+    if (USE_LUT) lane_cores32_lut<NP, false, false, true>(tb, wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+    else lane_cores32<NP, false, false, true>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
     return isect | (la << 6) | (lb << 12);
 }
 
@@ -263,9 +290,10 @@ __device__ __forceinline__ double stage_epilogue(uint32_t pk, double qa, double 
 
 // `last`: the round's last lane that holds a row of this kernel (uniform)
 template <int MEASURE>
-__device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta, uint32_t last,
-                                              uint16_t *s_code, uint32_t *s_word, double *s_val)
+__device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta,
+                                              uint32_t last, uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
+    constexpr bool LUT = stage_uses_lut<MEASURE>();
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
     // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any high bit leaves
@@ -289,29 +317,29 @@ __device__ __forceinline__ void stage_compute(const uint32_t (&wt)[8], const uin
 #if defined(STRSIM_EXP_NOCORE)   // diagnostic builds only: everything but the cores / the cores twice
         code = (la + tmin + tmax + (wide ? 1u : 0u)) * (uint32_t)QTAB_N + lb;
 #else
-        if (wide) code = stage_lev_code<7>(wt, la, wp, lb, tmin, tmax);
-        else code = stage_lev_code<5>(wt, la, wp, lb, tmin, tmax);
+        if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
 #if defined(STRSIM_EXP_CORE2X)
         {
             uint32_t wt2[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) wt2[q] = wt[q] ^ (code >> 31);
-            if (wide) code = stage_lev_code<7>(wt2, la, wp, lb, tmin, tmax);
-            else code = stage_lev_code<5>(wt2, la, wp, lb, tmin, tmax);
+            if (wide) code = stage_lev_code<7, LUT>(lut, wt2, la, wp, lb, tmin, tmax);
+            else code = stage_lev_code<5, LUT>(lut, wt2, la, wp, lb, tmin, tmax);
         }
 #endif
 #endif
         if (fast) s_code[idx] = (uint16_t)code;
     } else if (MEASURE == ALL_MEASURES) {
         unsigned long long pk;
-        if (wide) pk = stage_all_ints<7>(wt, la, wp, lb, tmin, tmax);
-        else pk = stage_all_ints<5>(wt, la, wp, lb, tmin, tmax);
+        if (wide) pk = stage_all_ints<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        else pk = stage_all_ints<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         if (fast) reinterpret_cast<unsigned long long *>(s_val)[idx] = pk;
     } else {
         // the measure's integers, 32 bits per row; its f64 epilogue runs in the store phase (stage_epilogue)
         uint32_t pk;
-        if (wide) pk = stage_ints<MEASURE, 7>(wt, la, wp, lb, tmin, tmax);
-        else pk = stage_ints<MEASURE, 5>(wt, la, wp, lb, tmin, tmax);
+        if (wide) pk = stage_ints<MEASURE, 7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        else pk = stage_ints<MEASURE, 5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         if (fast) s_word[idx] = pk;
     }
 }
@@ -327,13 +355,25 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
+    constexpr int STAGE_CAP = StageGeom<MEASURE>::CAP, STAGE_COL = StageGeom<MEASURE>::COL;
+    constexpr int STAGE_DMA_ITERS = StageGeom<MEASURE>::DMA_ITERS;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
+    // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
+    // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
+    constexpr bool LUT = stage_uses_lut<MEASURE>();
+    // The 1 KB behind each wave's tables holds 128 of the block's row descriptors (without tables: an array of their own).
+    static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
+    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : 16];
+    __shared__ uint2 s_desc_own[LUT ? 1 : B];
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
+    auto desc_at = [&](uint32_t p) -> uint2 * { // descriptor of position p of the length order
+        if (LUT) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
+        return s_desc_own + p;
+    };
     __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 4]; // offsets of the rows from the next block's start on
     __shared__ uint32_t s_cnt[32];
     __shared__ uint32_t s_left;                // rows of this workgroup's blocks that stay in the mask
     __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
-    __shared__ uint2 s_desc[B];
     // results wait in LDS for the coalesced store phase as the integers their f64 epilogue needs (all-ones = the row was not
     // computed here): Levenshtein a 16-bit table index, the other measures 32 bits, the five-output pass 64
     __shared__ uint16_t s_code[LEV ? B : 1];
@@ -401,7 +441,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     uint64_t row_end; // first row behind the current range
     uint64_t row0;    // first row of the block about to be processed
     {
-        const uint64_t lo = s_sched[0], hi = lo + s_sched[1];
+        const uint64_t lo = uniform(s_sched[0]), hi = lo + uniform(s_sched[1]); // (uniform: row counters live in SGPRs)
         row0 = lo * 64u < n ? lo * 64u : n;
         row_end = hi * 64u < n ? hi * 64u : n;
     }
@@ -409,6 +449,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     if (tid == 0u) grab(grab_lo, grab_lo, grab_sz); // (written to s_sched at the top of the first block)
     bool grab_pending = true;
 
+    EqLut lut; // this wave's match-mask tables
+    lut.lane4 = lane * 4u;
+    lut.krep = ((STRSIM_LDS_ADDR(&s_lut[0]) >> 8) + 16u * wv) * 0x01010101u;
     const uint32_t ldsOffA = STRSIM_LDS_ADDR(&s_off[0][0]), ldsOffB = STRSIM_LDS_ADDR(&s_off[1][0]);
     const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0]);
     const uint32_t wvu = uniform(wv);
@@ -643,7 +686,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const uint32_t base = __shfl(exc, skey[q], 32);
-                s_desc[base + srank[q]] = make_uint2(sd0[q], sd1[q]);
+                const uint32_t p = base + srank[q]; // position in length order
+                *desc_at(p) = make_uint2(sd0[q], sd1[q]);
             }
             nmine = uniform(__shfl(exc, NBK - 1, 32));
         }
@@ -656,7 +700,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         // ---- E: offsets DMA(j+1), in flight during the rounds
         uint64_t next_row0 = row0 + rows;
         if (next_row0 >= row_end) { // this range is done: move to the next one and ask for the one after it
-            const uint64_t lo = s_sched[0], hi = lo + s_sched[1];
+            const uint64_t lo = uniform(s_sched[0]), hi = lo + uniform(s_sched[1]); // (uniform: row counters live in SGPRs)
             next_row0 = lo * 64u < n ? lo * 64u : n;
             row_end = hi * 64u < n ? hi * 64u : n;
             if (tid == 0u) grab((uint32_t)lo, grab_lo, grab_sz);
@@ -682,7 +726,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #if STRSIM_STAGE_PRIO_WINDOWS
             __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
 #endif
-            const uint2 d = s_desc[r * 64u + lane];
+            const uint2 d = *desc_at(r * 64u + lane);
             uint32_t wt[8], wp[8];
             stage_window(s_bytes, d.x & 0xFFFFu, wt);
             stage_window(s_bytes, d.x >> 16, wp);
@@ -694,7 +738,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             __builtin_amdgcn_s_setprio(0);
 #endif
             const uint32_t in_round = nmine - r * 64u; // (>= 1)
-            stage_compute<MEASURE>(wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
+            stage_compute<MEASURE>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
             STAGE_STAMP(8);
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
@@ -741,8 +785,19 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #endif
 }
 
+// workgroups per CU (= waves per SIMD): 5 by LDS (28 KB) and registers (<= 96) without match-mask tables, 4 with them (40 KB;
+// Jaro's two passes want the registers anyway), 3 for the five-output pass (three cores' state at once)
+#ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
+#define STRSIM_STAGE_ALL_WAVES_PER_EU 3
+#endif
+template <int MEASURE> constexpr int stage_waves_per_eu()
+{
+    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : (stage_uses_lut<MEASURE>() ? 4 : 5);
+    return STRSIM_STAGE_WAVES_PER_EU < lim ? STRSIM_STAGE_WAVES_PER_EU : lim;
+}
+
 template <int MEASURE>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_WAVES_PER_EU))) void
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE>()))) void
 k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
              unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
@@ -751,12 +806,8 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
     lane_stage_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish);
 }
 
-// The five-output instantiation keeps the matching state of three cores alive at once: its own register budget
-// (4 waves per SIMD; its 33 KB of LDS admit 4 workgroups per CU anyway).
-#ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
-#define STRSIM_STAGE_ALL_WAVES_PER_EU 4
-#endif
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_STAGE_ALL_WAVES_PER_EU))) void
+// The five-output instantiation keeps the matching state of three cores alive at once and stages 64 bits per row.
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<ALL_MEASURES>()))) void
 k_lane_stage_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
                  unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstring>
 #include "strsim_lane_core.h"
+#include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
 #include "strsim_lane_sym.h"
 
@@ -59,14 +60,20 @@ extern "C" uint32_t harness_lev_snap(const uint8_t *a, uint32_t la, const uint8_
     std::memset(wb, fill, sizeof wb);
     std::memcpy(wa, a, la);
     std::memcpy(wb, b, lb);
+    // the bit-fill form and the table form (strsim_lane_lut.h) must agree; 0xFFFFFFFF when they do not
+    EqLut t{};
     if (np == 5) {
         uint32_t P[5];
         build_planes<5>(wb, P);
-        return lev_myers32_snap<5>(wa, la, tmin, tmax, P, lb);
+        lut_build<5>(t, P, 0xFFFFFFFFu);
+        const uint32_t d = lev_myers32_snap<5>(wa, la, tmin, tmax, P, lb);
+        return lev_myers32_lut<5>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
     }
     uint32_t P[7];
     build_planes<7>(wb, P);
-    return lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
+    lut_build<7>(t, P, 0xFFFFFFFFu);
+    const uint32_t d = lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
+    return lev_myers32_lut<7>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
 }
 
 // the one-loop cores (lane_cores32) with all three cores on, and each of them on its own: out[0..3] = dist, m, t, isect of
@@ -99,6 +106,28 @@ extern "C" int harness_cores32(const uint8_t *a, uint32_t la, const uint8_t *b, 
     if (d1 != d) return 1;
     if (m1 != m || t1 != t) return 2;
     if (is1 != is) return 3;
+    // the same cores with table masks (strsim_lane_lut.h): fused and one at a time
+    uint32_t d2 = 0, m2 = 0, t2 = 0, is2 = 0, d3 = 0, m3 = 0, t3 = 0, is3 = 0;
+    EqLut tb{};
+    if (np == 5) {
+        uint32_t P[5];
+        build_planes<5>(wb, P);
+        lut_build<5>(tb, P, 0xFFFFFFFFu);
+        lane_cores32_lut<5, true, true, true>(tb, wa, la, tmin, tmax, lb, P, d2, m2, t2, is2);
+        lane_cores32_lut<5, true, false, false>(tb, wa, la, tmin, tmax, lb, P, d3, x, x, x);
+        lane_cores32_lut<5, false, true, false>(tb, wa, la, tmin, tmax, lb, P, x, m3, t3, x);
+        lane_cores32_lut<5, false, false, true>(tb, wa, la, tmin, tmax, lb, P, x, x, x, is3);
+    } else {
+        uint32_t P[7];
+        build_planes<7>(wb, P);
+        lut_build<7>(tb, P, 0xFFFFFFFFu);
+        lane_cores32_lut<7, true, true, true>(tb, wa, la, tmin, tmax, lb, P, d2, m2, t2, is2);
+        lane_cores32_lut<7, true, false, false>(tb, wa, la, tmin, tmax, lb, P, d3, x, x, x);
+        lane_cores32_lut<7, false, true, false>(tb, wa, la, tmin, tmax, lb, P, x, m3, t3, x);
+        lane_cores32_lut<7, false, false, true>(tb, wa, la, tmin, tmax, lb, P, x, x, x, is3);
+    }
+    if (d2 != d || m2 != m || t2 != t || is2 != is) return 4;
+    if (d3 != d || m3 != m || t3 != t || is3 != is) return 5;
     return 0;
 }
 
