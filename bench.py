@@ -182,6 +182,8 @@ def main():
     ctx = S.Context(local_rank, stream=compute_stream.cuda_stream)
     assert ctx.stream == compute_stream.cuda_stream
     gather = world > 1 and not a.no_gather
+    if gather:
+        ctx.set_stream_ordered(True)  # the gather reads a step's results behind an event, without retiring the call first
     shipper = None
     gather_note = None
     if gather:
@@ -271,10 +273,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ops0 = ctx.enqueued_ops
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     drain()
+    ops_per_step = (ctx.enqueued_ops - ops0) / max(a.steps, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -343,7 +347,7 @@ def main():
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
                        "gather_verified": gather_ok, "gather_note": gather_note,
-                       "rows_on_wave_kernel": wave_rows},
+                       "rows_on_wave_kernel": wave_rows, "enqueued_kernels_and_copies_per_step": ops_per_step},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_read_bytes": read_bytes, "algorithmic_write_bytes": write_bytes,

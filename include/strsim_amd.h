@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010002u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths */
+#define STRSIM_ABI_VERSION 0x00010003u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows) */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -89,10 +89,19 @@ STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
  * every slot; validity is combined by the caller (the plugin layer does it).
  *
  * The call is asynchronous: it returns once the kernels are enqueued on the context's stream.
- * Results are complete after strsim_ctx_synchronize() (or after later work on the same stream for
- * rows whose strings are <= STRSIM_WAVE_PATH_MAX_BYTES; rows with a longer string are finished by a
- * second pass that strsim_ctx_synchronize() launches).  All buffers of a call must stay valid until
- * strsim_ctx_synchronize() has returned.
+ * Results are complete after strsim_ctx_synchronize() (or strsim_ctx_retire_oldest() of this call).
+ * All buffers of a call must stay valid until then.
+ *
+ * What the stream alone guarantees (ABI 1.3): a context whose last retired call had every row finished
+ * by the one-pair-per-lane kernel (both strings <= STRSIM_LANE_PATH_MAX_BYTES, ASCII -- the common
+ * column) enqueues the NEXT call as that kernel alone: ONE launch instead of five.  If such a call
+ * does hold longer or non-ASCII rows, the kernels for them are launched when the call is retired, i.e.
+ * AFTER anything the caller enqueued behind the call -- strsim_ctx_last_late_rows() tells, and the calls
+ * after it enqueue all their kernels up front again.  A caller that consumes results in stream order
+ * without retiring the call first (a collective on a side stream behind an event) switches this off with
+ * strsim_ctx_set_stream_ordered(ctx, 1): then every row of strings <= STRSIM_WAVE_PATH_MAX_BYTES is
+ * complete in stream order, as in ABI 1.2; rows with a longer string are always finished by a pass that
+ * strsim_ctx_synchronize() / strsim_ctx_retire_oldest() launches.
  */
 STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
@@ -120,6 +129,10 @@ STRSIM_API int strsim_pairs_device_all(strsim_ctx_t *ctx,
 
 /* Wait for everything enqueued through this context and surface any deferred error. */
 STRSIM_API int strsim_ctx_synchronize(strsim_ctx_t *ctx);
+
+/* 1: every call enqueues all its kernels up front (results of rows <= STRSIM_WAVE_PATH_MAX_BYTES complete in stream order);
+ * 0 (default): calls that are expected to need the first kernel only are one launch (see strsim_pairs_device). */
+STRSIM_API int strsim_ctx_set_stream_ordered(strsim_ctx_t *ctx, int enable);
 
 /*
  * Same contract with HOST-RESIDENT buffers: stages the shards to the device, runs the kernels and
@@ -172,6 +185,16 @@ STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
  * STRSIM_WAVE_PATH_MAX_BYTES: their results were written by the second pass that synchronize runs, i.e. AFTER anything
  * the caller enqueued on the stream behind the call (a caller that copies results out early re-copies when > 0). */
 STRSIM_API uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *ctx);
+
+/* Rows of the calls retired by the last strsim_ctx_synchronize() / strsim_ctx_retire_oldest() whose results were written by a
+ * pass launched from there -- the slow-row kernels of a one-launch call that did hold such rows, and the long-string pass --
+ * i.e. AFTER anything the caller enqueued on the stream behind the call (a caller that copied results out early copies again
+ * when this is > 0).  >= strsim_ctx_last_long_rows(). */
+STRSIM_API uint64_t strsim_ctx_last_late_rows(strsim_ctx_t *ctx);
+
+/* Kernels and device copies this context has enqueued for pair calls since it was created (a call of a column whose rows
+ * all fit the one-pair-per-lane kernel adds 1; a call with all kernels up front 5; introspection for tests and benches). */
+STRSIM_API uint64_t strsim_ctx_enqueued_ops(strsim_ctx_t *ctx);
 
 /*
  * Lossless 16-bit transport codec for result columns (csrc/strsim_codec.hip).  A similarity of two strings of at

@@ -835,11 +835,11 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         } else {
             HIP_OR_FAIL(hipEventSynchronize(sl.ev_results));
             // (the oldest call in flight is this slice's: slices are launched and finished in order)
-            if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the long-string pass
+            if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the deferred slow-row and long-string passes
         }
         tm.stop(tm.t_wait);
         const bool via_slot = sl.direct || !out_pinned;
-        if (strsim_ctx_last_long_rows(ctx) != 0 && !sl.direct) { // rows finished by that pass: fetch the column again
+        if (strsim_ctx_last_late_rows(ctx) != 0 && !sl.direct) { // rows finished by a pass launched just now: fetch the column again
             tm.start();
             HIP_OR_FAIL(hipMemcpyAsync(via_slot ? sl.h_out.p : static_cast<void *>(out + sl.r0), sl.d_out.p, sl.rows * sizeof(double),
                                        hipMemcpyDeviceToHost, stream));

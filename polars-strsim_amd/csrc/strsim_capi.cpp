@@ -4,6 +4,7 @@
 // (reference src/expressions/strsim.rs:41-107): shape rule, literal broadcast, row partition.
 // There is no CPU compute path in this library: without a HIP device every compute call fails.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <algorithm>
 
 #include <cstdarg>
@@ -57,9 +58,12 @@ struct strsim_ctx {
     int stage_wg_per_cu = 5;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pairs instead of k_lane_stage (A/B runs)
     int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
     int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
-    // workspace (grow-only)
-    unsigned long long *slowmask = nullptr;
-    size_t slowmask_cap = 0; // entries
+    // workspace (grow-only).  The "not finished yet" masks (+ backup + work list) of a call: a ring of MASKBUFS buffers, slot s
+    // uses buffer s % MASKBUFS -- a call whose slow-row kernels are launched late (below) needs its mask intact while
+    // younger calls run
+    static constexpr int MASKBUFS = 4;
+    unsigned long long *slowmask[MASKBUFS] = {};
+    size_t slowmask_cap[MASKBUFS] = {}; // bytes
     // per-call deferred state: a ring of status words + event triples, so calls can be enqueued
     // back to back without a host sync; the ring is drained by strsim_ctx_synchronize()
     static constexpr int RING = 32;
@@ -72,6 +76,16 @@ struct strsim_ctx {
     size_t pin_cap = 0;
     hipEvent_t ev[RING][3] = {};
     bool slot_pending[RING] = {};
+    // A call whose lane kernel is EXPECTED to leave nothing behind (the last retired call did not: short ASCII columns) is
+    // ONE kernel launch: k_lane_stage's last workgroup publishes lane_left and the ticket itself.  If it did leave rows, the
+    // slow-row kernels are launched when the call is retired (strsim_ctx_synchronize / strsim_ctx_retire_oldest) -- like
+    // the long-string pass -- and the next calls enqueue the whole chain up front again.
+    bool slot_deferred[RING] = {};
+    bool expect_slow = false;
+    bool stream_ordered = false;   // strsim_ctx_set_stream_ordered: never defer
+    uint64_t last_late_rows = 0;   // rows finished by a pass launched from synchronize / retire (deferred + long-string)
+    hipEvent_t ev_late[2] = {};    // timing of a deferred slow pass
+    uint64_t enqueued_ops = 0;     // kernels + copies this context has put on its stream for pair calls (strsim_ctx_enqueued_ops)
     uint32_t slot_ticket[RING] = {}; // what the device writes into status_host[slot].ticket when the call's status block is out
     uint32_t ticket_seq = 0;
     bool slot_timed[RING] = {};
@@ -158,20 +172,74 @@ static bool ctx_slot_published(const strsim_ctx *c, int s)
     return seen == c->slot_ticket[s];
 }
 
+// Wait until the call in slot s has completed (its ticket has arrived), without waiting for younger calls: poll the
+// host-mapped ticket for a while, then fall back on the stream.
+static int ctx_wait_published(strsim_ctx *c, int s)
+{
+    for (int spin = 0; spin < 2000000; ++spin) {
+        if (ctx_slot_published(c, s)) return STRSIM_OK;
+        if ((spin & 63) == 63) sched_yield();
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return STRSIM_OK;
+}
+
+static constexpr uint32_t LANE_LEFT_UNKNOWN = 0xFFFFFFFFu; // the call's first kernel does not report (k_lane_lit, k_lane_pairs)
+
+// The slow-row kernels of a call that was enqueued as its lane kernel alone and left rows behind: launched now, behind
+// whatever the stream holds, and waited for.
+static int ctx_run_deferred(strsim_ctx *c, int s)
+{
+    LaunchArgs a = c->slot_args[s];
+    a.ev_lane0 = a.ev_lane1 = a.ev_wave1 = nullptr;
+    a.publish_host = nullptr;
+    a.publish_ticket = 0u;
+    const bool timed = c->slot_timed[s];
+    if (timed) {
+        for (int i = 0; i < 2; ++i)
+            if (!c->ev_late[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_late[i], hipEventDisableSystemFence));
+        HIP_TRY(hipEventRecord(c->ev_late[0], c->stream));
+    }
+    hipError_t e;
+    if (c->slot_measure[s] == STRSIM_NUM_MEASURES) {
+        const uint64_t nchunks = (a.n + 63u) >> 6;
+        e = launch_slow_all_only(a, c->slot_outs[s], a.slowmask + nchunks);
+    } else {
+        e = launch_slow_only(c->slot_measure[s], a);
+    }
+    if (e != hipSuccess) return hip_fail(e, "kernel launch (slow rows of a retired call)");
+    c->enqueued_ops += (c->slot_measure[s] == STRSIM_NUM_MEASURES ? 20u : 3u) + 1u; // + the status copy
+    if (timed) HIP_TRY(hipEventRecord(c->ev_late[1], c->stream));
+    if (++c->ticket_seq == 0u) c->ticket_seq = 1u;
+    c->slot_ticket[s] = c->ticket_seq;
+    c->status_host[s].ticket = 0u;
+    HIP_TRY(launch_publish_status(c->status + s, c->status_host_dev + s, c->slot_ticket[s], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (timed) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_late[0], c->ev_late[1]));
+        c->wave_ms += ms;
+    }
+    return STRSIM_OK;
+}
+
 static int ctx_retire_slot(strsim_ctx *c, int s)
 {
     int rc = STRSIM_OK;
     c->slot_pending[s] = false;
     if (!ctx_slot_published(c, s)) { // (cannot happen behind a stream synchronise; strsim_ctx_retire_oldest checks before it gets here)
-        c->slot_timed[s] = false;
+        c->slot_timed[s] = c->slot_deferred[s] = false;
         set_error("internal: the status block of a completed call was not published (slot %d)", s);
         return STRSIM_ERR_INTERNAL;
     }
+    const uint32_t left = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].lane_left);
+    if (left != LANE_LEFT_UNKNOWN) c->expect_slow = left != 0u; // what the next call on this context is enqueued for
     if (c->slot_timed[s]) {
-        c->slot_timed[s] = false;
         float a = 0, b = 0;
-        hipError_t e = hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
+        // (the ticket says the kernels are done; the event right behind them may be a moment later)
+        hipError_t e = hipEventSynchronize(c->ev[s][c->slot_deferred[s] ? 1 : 2]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&a, c->ev[s][0], c->ev[s][1]);
+        if (e == hipSuccess && !c->slot_deferred[s]) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
         if (e == hipSuccess) {
             c->lane_ms += a; c->wave_ms += b;
             c->lane_launches++; c->wave_launches++;
@@ -179,10 +247,21 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
             rc = hip_fail(e, "hipEventElapsedTime");
         }
     }
+    if (c->slot_deferred[s] && left != 0u && rc == STRSIM_OK) {
+        rc = ctx_run_deferred(c, s);
+        if (rc == STRSIM_OK && !ctx_slot_published(c, s)) {
+            set_error("internal: the status block of a deferred pass was not published (slot %d)", s);
+            rc = STRSIM_ERR_INTERNAL;
+        }
+        c->last_late_rows += left;
+    }
+    c->slot_timed[s] = c->slot_deferred[s] = false;
+    if (rc != STRSIM_OK) return rc;
     const DevStatus &st = c->status_host[s];
     c->last_wave_rows = st.wave_rows;
     c->last_long_rows += st.huge_rows;
-    if (st.huge_rows != 0 && rc == STRSIM_OK) rc = ctx_run_huge(c, s, st);
+    c->last_late_rows += st.huge_rows;
+    if (st.huge_rows != 0) rc = ctx_run_huge(c, s, st);
     return rc;
 }
 
@@ -191,11 +270,12 @@ static int ctx_drain(strsim_ctx *c)
 {
     int rc = STRSIM_OK;
     c->last_long_rows = 0;
+    c->last_late_rows = 0;
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
         if (rc == STRSIM_OK) rc = ctx_retire_slot(c, s);
-        else c->slot_pending[s] = c->slot_timed[s] = false;
+        else c->slot_pending[s] = c->slot_timed[s] = c->slot_deferred[s] = false;
     }
     return rc;
 }
@@ -297,7 +377,8 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
         for (int i = 0; i < 3; ++i)
             if (c->ev[s][i]) (void)hipEventDestroy(c->ev[s][i]);
     for (int i = 0; i < 5; ++i) if (c->stage[i]) (void)hipFree(c->stage[i]);
-    if (c->slowmask) (void)hipFree(c->slowmask);
+    for (int i = 0; i < strsim_ctx::MASKBUFS; ++i) if (c->slowmask[i]) (void)hipFree(c->slowmask[i]);
+    for (int i = 0; i < 2; ++i) if (c->ev_late[i]) (void)hipEventDestroy(c->ev_late[i]);
     if (c->qtab) (void)hipFree(c->qtab);
     if (c->sched) (void)hipFree(c->sched);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
@@ -362,22 +443,45 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         if (rc) return rc;
     }
     const uint64_t nchunks = (n + 63) >> 6;
+    // the slot's mask buffer: whoever used it last (MASKBUFS calls ago, or further back) must have been retired -- a call
+    // that is still waiting for its slow-row kernels needs its mask.  Wait for THAT call only (its ticket), not for the
+    // stream: the younger calls keep the GPU busy meanwhile.
+    const int mb = slot % strsim_ctx::MASKBUFS;
+    for (int k = 0; k < strsim_ctx::RING; ++k) {
+        const int s = (c->head + k) % strsim_ctx::RING; // oldest first
+        if (!c->slot_pending[s] || s % strsim_ctx::MASKBUFS != mb) continue;
+        // retire everything up to and including s, in order
+        rc = ctx_wait_published(c, s);
+        if (rc) return rc;
+        for (int j = 0; j <= k; ++j) {
+            const int t = (c->head + j) % strsim_ctx::RING;
+            if (!c->slot_pending[t]) continue;
+            rc = ctx_retire_slot(c, t);
+            if (rc) return rc;
+        }
+    }
     // mask + backup (five-measure call) + the work list of k_lane_utf8 (one u32 per chunk)
-    rc = ctx_reserve((void **)&c->slowmask, &c->slowmask_cap, 2 * nchunks * sizeof(unsigned long long) + nchunks * sizeof(uint32_t));
-    if (rc) return rc;
+    {
+        void *p = c->slowmask[mb];
+        rc = ctx_reserve(&p, &c->slowmask_cap[mb], 2 * nchunks * sizeof(unsigned long long) + nchunks * sizeof(uint32_t));
+        c->slowmask[mb] = static_cast<unsigned long long *>(p);
+        if (rc) return rc;
+    }
     // (the status block of the slot is cleared by the first kernel of the call, k_lane_pairs)
     if (++c->ticket_seq == 0u) c->ticket_seq = 1u;
     c->slot_ticket[slot] = c->ticket_seq;
-    c->status_host[slot].ticket = 0u; // (the slot is not pending: nothing on the device writes this block now)
+    memset(&c->status_host[slot], 0, sizeof(DevStatus)); // (the slot is not pending: nothing on the device writes this block now)
+    c->status_host[slot].lane_left = LANE_LEFT_UNKNOWN;
 
     LaunchArgs la;
     la.offA = a_off; la.valA = a_val; la.rowsA = a_rows;
     la.offB = b_off; la.valB = b_val; la.rowsB = b_rows;
     la.out = outs[0]; la.n = n;
-    la.slowmask = c->slowmask; la.status = c->status + slot; la.stream = c->stream;
+    la.slowmask = c->slowmask[mb]; la.status = c->status + slot; la.stream = c->stream;
     la.sched = c->sched + 4 * slot;
     la.publish_host = nullptr;
-    la.worklist = reinterpret_cast<uint32_t *>(c->slowmask + 2 * nchunks);
+    la.publish_ticket = 0u;
+    la.worklist = reinterpret_cast<uint32_t *>(c->slowmask[mb] + 2 * nchunks);
     la.qtab = c->qtab;
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
@@ -407,28 +511,31 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
             if (!c->ev[slot][i]) HIP_TRY(hipEventCreateWithFlags(&c->ev[slot][i], hipEventDisableSystemFence));
         la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
     }
-    if (eager && !all && la.stage_grid > 0 && !c->timing) {
+    const bool reports = lane_kernel_reports(measure, la); // k_lane_stage: its last workgroup writes lane_left (and a ticket)
+    if (eager && !all && reports && !c->timing) {
         // Small call the caller is going to wait for anyway: launch the one-pair-per-lane kernel alone, let its last
         // workgroup report how many rows it left (host-mapped status word) and wait for it.  Usually that is none --
         // short ASCII strings -- and the call is done after ONE kernel launch instead of five (the three slow-row kernels
         // and the status copy cost ~4 us each even when they find nothing to do).
-        la.no_literal_path = true; // (k_lane_stage reports; it broadcasts a literal itself)
         la.publish_host = c->status_host_dev + slot;
-        c->status_host[slot].lane_left = 0xFFFFFFFFu;
         hipError_t e0 = launch_lane_only(measure, la);
         if (e0 != hipSuccess) return hip_fail(e0, "kernel launch");
+        c->enqueued_ops += 1u;
         HIP_TRY(hipStreamSynchronize(c->stream));
         const uint32_t left = *reinterpret_cast<volatile uint32_t *>(&c->status_host[slot].lane_left);
         if (getenv("STRSIM_TRACE")) fprintf(stderr, "[strsim] eager call: %llu rows, %u left behind the lane kernel\n", (unsigned long long)n, left);
         if (left == 0u) {
             c->last_wave_rows = 0;
             c->last_long_rows = 0;
+            c->last_late_rows = 0;
             return STRSIM_OK; // nothing pending: strsim_ctx_synchronize() has nothing to retire for this call
         }
         la.publish_host = nullptr;
         e0 = launch_slow_only(measure, la);
         if (e0 != hipSuccess) return hip_fail(e0, "kernel launch");
+        c->enqueued_ops += 4u;
         c->slot_timed[slot] = false;
+        c->slot_deferred[slot] = false;
         c->slot_args[slot] = la;
         c->slot_measure[slot] = measure;
         for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = nullptr;
@@ -437,13 +544,23 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         c->head = (slot + 1) % strsim_ctx::RING;
         return STRSIM_OK;
     }
-    hipError_t e = all ? launch_pairs_all(la, outs, c->slowmask + nchunks) : launch_pairs(measure, la);
+    if (reports) la.publish_host = c->status_host_dev + slot; // lane_left reaches the host either way: it sets expect_slow
+    const bool defer = reports && !c->expect_slow && !c->stream_ordered;
+    hipError_t e;
+    if (defer) {
+        la.publish_ticket = c->slot_ticket[slot];
+        e = all ? launch_lane_all_only(la, outs) : launch_lane_only(measure, la);
+    } else {
+        e = all ? launch_pairs_all(la, outs, c->slowmask[mb] + nchunks) : launch_pairs(measure, la);
+    }
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    c->enqueued_ops += defer ? 1u : (all ? 22u : 5u); // lane kernel | + three slow-row kernels (x 5, + 5 mask copies) + status copy
     c->slot_timed[slot] = c->timing;
+    c->slot_deferred[slot] = defer;
     c->slot_args[slot] = la;
     c->slot_measure[slot] = measure;
     for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = all ? outs[q] : nullptr;
-    HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->slot_ticket[slot], c->stream));
+    if (!defer) HIP_TRY(launch_publish_status(c->status + slot, c->status_host_dev + slot, c->slot_ticket[slot], c->stream));
     c->slot_pending[slot] = true;
     c->head = (slot + 1) % strsim_ctx::RING;
     return STRSIM_OK;
@@ -496,6 +613,7 @@ int strsim_ctx_retire_oldest(strsim_ctx_t *c)
     int rc = ctx_set_device(c);
     if (rc) return rc;
     c->last_long_rows = 0;
+    c->last_late_rows = 0;
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
@@ -608,5 +726,14 @@ int strsim_ctx_timing_read(strsim_ctx_t *c, double *lane_ms, uint64_t *lane_laun
 
 uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *c) { return c ? c->last_wave_rows : 0; }
 uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *c) { return c ? c->last_long_rows : 0; }
+uint64_t strsim_ctx_last_late_rows(strsim_ctx_t *c) { return c ? c->last_late_rows : 0; }
+uint64_t strsim_ctx_enqueued_ops(strsim_ctx_t *c) { return c ? c->enqueued_ops : 0; }
+
+int strsim_ctx_set_stream_ordered(strsim_ctx_t *c, int enable)
+{
+    if (!c) { set_error("strsim_ctx_set_stream_ordered: ctx is NULL"); return STRSIM_ERR_ARG; }
+    c->stream_ordered = enable != 0;
+    return STRSIM_OK;
+}
 
 } // extern "C"

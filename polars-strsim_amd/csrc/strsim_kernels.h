@@ -52,7 +52,8 @@ struct LaunchArgs {
     const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of k_lane_pairs (device)
     DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
     uint32_t *sched;              // k_lane_stage: four zeroed words (range counter, finished workgroups, rows left, -); left zeroed by the kernel
-    DevStatus *publish_host;      // eager small calls: the last workgroup of k_lane_stage writes lane_left there (host-mapped), else nullptr
+    DevStatus *publish_host;      // the last workgroup of k_lane_stage writes lane_left there (host-mapped), else nullptr
+    uint32_t publish_ticket;      // != 0: ... and then this ticket: the call consists of that kernel alone
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     bool no_literal_path;         // A/B runs: a literal call takes k_lane_stage like any other
@@ -67,6 +68,12 @@ hipError_t launch_pairs(int measure, const LaunchArgs &a);
 // the two halves of launch_pairs for a call that looks at lane_left in between (small calls: usually nothing is left)
 hipError_t launch_lane_only(int measure, const LaunchArgs &a);
 hipError_t launch_slow_only(int measure, const LaunchArgs &a);
+// the same two halves of launch_pairs_all
+hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5]);
+hipError_t launch_slow_all_only(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);
+// does a call of `measure` (STRSIM_NUM_MEASURES = all five) with these arguments start with k_lane_stage (whose last workgroup
+// can report lane_left and the ticket)?  Not when a literal takes k_lane_lit, not on the k_lane_pairs A/B path.
+bool lane_kernel_reports(int measure, const LaunchArgs &a);
 
 // All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
 hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);

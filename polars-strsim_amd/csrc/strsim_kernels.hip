@@ -26,6 +26,7 @@
 // Built with -ffp-contract=off so the f64 epilogues are bit-identical to the Rust source.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <type_traits>
 
@@ -1810,6 +1811,21 @@ static void wide_geometry(const LaunchArgs &a, int span, uint32_t &sps, unsigned
     grid = (unsigned)(nsuper < (uint64_t)a.wide_grid_cap ? nsuper : (uint64_t)a.wide_grid_cap);
 }
 
+// Persistent workgroups of k_lane_stage for a frame of nsb blocks: all that are resident when the frame is large; a frame
+// of a few blocks per workgroup runs faster on FEWER workgroups -- the pipeline of a workgroup (offsets and bytes of the next
+// block in flight behind the current one) only pays from its second block on, and every workgroup pays the prologue: a
+// 1 M-row call takes 0.085 ms on 5 workgroups per CU and 0.051 ms on 2.  So: about four blocks per workgroup, but at least
+// one workgroup per CU while there are blocks for them.
+static uint64_t stage_launch_size(uint64_t nsb, uint64_t resident, uint64_t cus)
+{
+    static const uint64_t per = [] { const char *e = getenv("STRSIM_STAGE_BLOCKS_PER_WG"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 4); }(); // (tuning knob)
+    uint64_t g = nsb / per;
+    const uint64_t floor_ = nsb < cus ? nsb : cus;
+    if (g < floor_) g = floor_;
+    if (g > resident) g = resident;
+    return g ? g : 1u;
+}
+
 template <int M>
 static void launch_lane_t(const LaunchArgs &a)
 {
@@ -1840,9 +1856,9 @@ static void launch_lane_t(const LaunchArgs &a)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; a measure that runs fewer gets its share)
         const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
-        const uint64_t gs = nsb < res ? nsb : res;
+        const uint64_t gs = stage_launch_size(nsb, res, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
         hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
+                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
     } else {
         hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
@@ -1923,10 +1939,9 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
 
 // All five measures of one frame: one fused lane kernel (five outputs), then the slow-row kernels per measure,
 // each starting from the same mask (k_lane_wide clears what it finishes, so the mask is restored in between).
-hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup)
+hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5])
 {
     if (a.n == 0) return hipSuccess;
-    const uint64_t nchunks = (a.n + 63u) >> 6;
     const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
     const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
     OutPtrs op{};
@@ -1936,14 +1951,22 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
         // one staged pass, five outputs (strsim_lane_stage.h, MEASURE = ALL_MEASURES)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         const uint64_t cap = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<ALL_MEASURES>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU; // resident workgroups
-        const uint64_t gs = nsb < cap ? nsb : cap;
+        const uint64_t gs = stage_launch_size(nsb, cap, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
         hipLaunchKernelGGL(k_lane_stage_all, dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA,
-                           a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host);
+                           a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host,
+                           a.publish_ticket);
     } else {
         hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
                            a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_slow_all_only(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup)
+{
+    if (a.n == 0) return hipSuccess;
+    const uint64_t nchunks = (a.n + 63u) >> 6;
     hipError_t e = hipMemcpyAsync(mask_backup, a.slowmask, nchunks * sizeof(unsigned long long), hipMemcpyDeviceToDevice, a.stream);
     if (e != hipSuccess) return e;
     launch_slow_kernels<LEVENSHTEIN>(a, outs[LEVENSHTEIN]);
@@ -1959,6 +1982,22 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     }
     if (a.ev_wave1) (void)hipEventRecord(a.ev_wave1, a.stream);
     return hipGetLastError();
+}
+
+hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup)
+{
+    hipError_t e = launch_lane_all_only(a, outs);
+    if (e != hipSuccess) return e;
+    return launch_slow_all_only(a, outs, mask_backup);
+}
+
+bool lane_kernel_reports(int measure, const LaunchArgs &a)
+{
+    if (a.stage_grid <= 0) return false;
+    if (measure == 5) return true; // the five-output pass has no literal kernel
+    const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
+    const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
+    return !(lit_path && !a.no_literal_path);
 }
 
 hipError_t launch_lane_only(int measure, const LaunchArgs &a)
@@ -2009,8 +2048,10 @@ __global__ void k_publish_status(const DevStatus *__restrict__ src, DevStatus *_
 {
     const unsigned *s = reinterpret_cast<const unsigned *>(src);
     unsigned *d = reinterpret_cast<unsigned *>(dst);
-    constexpr unsigned TICKET_WORD = offsetof(DevStatus, ticket) / 4;
-    if (threadIdx.x < sizeof(DevStatus) / 4 && threadIdx.x != TICKET_WORD) __builtin_nontemporal_store(s[threadIdx.x], d + threadIdx.x);
+    // (lane_left belongs to k_lane_stage's last workgroup, which writes the host copy itself; the ticket goes last)
+    constexpr unsigned TICKET_WORD = offsetof(DevStatus, ticket) / 4, LEFT_WORD = offsetof(DevStatus, lane_left) / 4;
+    if (threadIdx.x < sizeof(DevStatus) / 4 && threadIdx.x != TICKET_WORD && threadIdx.x != LEFT_WORD)
+        __builtin_nontemporal_store(s[threadIdx.x], d + threadIdx.x);
     __threadfence_system();
     // the ticket goes last: a host that sees it sees the block (one wave: the stores above were issued before this one)
     if (threadIdx.x == 0u) __hip_atomic_store(&dst->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

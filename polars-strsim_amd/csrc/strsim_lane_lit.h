@@ -139,7 +139,9 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         if (k == 0u) k = 1u;
         return uniform(k * 64u < avail ? k * 64u : avail);
     };
-    auto dma_bytes = [&](uint32_t base, uint32_t mis, uint32_t end, uint32_t buf) -> uint32_t { // -> bytes the strings may use
+    // (tail_lo .. tail_hi: the part of the copy that lies past the column's last byte -- zeroed once the copy has landed, by the
+    //  lane that copied the column's last chunk; see k_lane_stage)
+    auto dma_bytes = [&](uint32_t base, uint32_t mis, uint32_t end, uint32_t buf, uint32_t &tail_lo, uint32_t &tail_hi) -> uint32_t { // -> bytes the strings may use
         const uint32_t span = end - base + mis;
         const uint32_t staged = ((span < (uint32_t)LIT_CAP ? span : (uint32_t)LIT_CAP) + 15u) & ~15u;
         // + the 32 bytes behind the block when the column has them, then 32 zeros (see k_lane_stage: no stale LDS in a window)
@@ -151,6 +153,8 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
             if (tid + (uint32_t)it * LIT_BLOCK < chunks)
                 lds_dma_b128(g + 16 * it * LIT_BLOCK, tid16, ldsBytes + buf * (uint32_t)LIT_COL + 16u * ((uint32_t)it * LIT_BLOCK + wvu * 64u));
         if (tid < 2u) *reinterpret_cast<uint4 *>(&s_bytes[buf][(chunks << 4) + tid * 16u]) = make_uint4(0u, 0u, 0u, 0u);
+        tail_lo = left;
+        tail_hi = chunks << 4;
         return staged;
     };
     // results of a block, coalesced; straight-line passes as in k_lane_stage (all table loads of a thread before the first wait)
@@ -205,7 +209,8 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
     lds_barrier();
     uint32_t base, mis;
     uint32_t rows = cut(row0, 0u, base, mis);
-    uint32_t staged = dma_bytes(base, mis, uniform(s_off[0][rows]), 0u);
+    uint32_t tail_lo = 0u, tail_hi = 0u;
+    uint32_t staged = dma_bytes(base, mis, uniform(s_off[0][rows]), 0u, tail_lo, tail_hi);
     if (row0 + rows < row_end) dma_offsets(row0 + rows, 1u);
     uint64_t prev_row0 = 0;
     uint32_t prev_rows = 0, prev_bb = 0;
@@ -214,14 +219,16 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         const uint32_t ob = j % 3u, bb = j & 1u;
         // ---- bytes(j) and offsets(j+1) have landed; everybody is done with block j-1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tail_lo < tail_hi && tid == (((tail_hi >> 4) - 1u) & (uint32_t)(LIT_BLOCK - 1)))
+            for (uint32_t b = tail_lo; b < tail_hi; ++b) s_bytes[bb][b] = 0;
         lds_barrier();
         // ---- block j+1: cut it, start its bytes and the offsets of block j+2
         const uint64_t next_row0 = row0 + rows;
-        uint32_t nbase = 0u, nmis = 0u, nrows = 0u, nstaged = 0u;
+        uint32_t nbase = 0u, nmis = 0u, nrows = 0u, nstaged = 0u, ntail_lo = 0u, ntail_hi = 0u;
         if (next_row0 < row_end) {
             const uint32_t ob1 = (j + 1u) % 3u;
             nrows = cut(next_row0, ob1, nbase, nmis);
-            nstaged = dma_bytes(nbase, nmis, uniform(s_off[ob1][nrows]), bb ^ 1u);
+            nstaged = dma_bytes(nbase, nmis, uniform(s_off[ob1][nrows]), bb ^ 1u, ntail_lo, ntail_hi);
             if (next_row0 + nrows < row_end) dma_offsets(next_row0 + nrows, (j + 2u) % 3u);
         }
         // ---- results of block j-1
@@ -294,7 +301,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         prev_rows = rows;
         prev_bb = bb;
         if (next_row0 >= row_end) break;
-        row0 = next_row0; rows = nrows; base = nbase; mis = nmis; staged = nstaged;
+        row0 = next_row0; rows = nrows; base = nbase; mis = nmis; staged = nstaged; tail_lo = ntail_lo; tail_hi = ntail_hi;
     }
     lds_barrier();
     store_block(prev_row0, prev_rows, prev_bb);

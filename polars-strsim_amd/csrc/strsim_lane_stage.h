@@ -46,6 +46,15 @@
 #ifndef STRSIM_STAGE_LUT
 #define STRSIM_STAGE_LUT 0x26 // bit m set: measure m (bit 5: the five-output pass) takes its match masks from per-lane LDS tables
 #endif                       //   (strsim_lane_lut.h) instead of bit fills.  Default: Jaro, Jaro-Winkler, the five-output pass.
+#ifndef STRSIM_STAGE_RANGE_MAX
+#define STRSIM_STAGE_RANGE_MAX 64   // chunks of 64 rows a workgroup takes from the device-wide counter at a time, at most
+#endif
+#ifndef STRSIM_STAGE_RANGE_DIV
+#define STRSIM_STAGE_RANGE_DIV 4    // ... = what is left / (this x workgroups) once less than RANGE_MAX x this x workgroups are left
+#endif
+#ifndef STRSIM_STAGE_RANGE_MIN_BLOCKS
+#define STRSIM_STAGE_RANGE_MIN_BLOCKS 2 // ... and at least this many blocks (1: a 3 M-row call 132 us instead of 102, cfg2 +2 %: the counter is one contended address)
+#endif
 #ifndef STRSIM_STAGE_PRIO
 #define STRSIM_STAGE_PRIO 1
 #endif
@@ -86,6 +95,11 @@ constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and blo
 // Jaro 41 -> 45.6 G pairs/s on cfg2's lengths.  Levenshtein, Jaccard and Dice are issue-bound at 5 workgroups per CU and
 // latency-bound at 4: 28 % fewer vector instructions bought nothing there.
 template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_LUT >> MEASURE) & 1) != 0; } // (5: five outputs)
+// ... and which use the SMALL table (planes 3..4 only, 4 KB of LDS per workgroup: still five workgroups per CU)
+#ifndef STRSIM_STAGE_MLUT
+#define STRSIM_STAGE_MLUT 0x00 // none: measured on cfg2, Levenshtein 1.42 -> 1.53 ms (the extra LDS reads cost more than the bit fills they replace)
+#endif
+template <int MEASURE> constexpr bool stage_uses_mlut() { return !stage_uses_lut<MEASURE>() && ((STRSIM_STAGE_MLUT >> MEASURE) & 1) != 0; }
 
 // staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
 template <int MEASURE> struct StageGeom {
@@ -181,20 +195,23 @@ __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
 }
 
 // Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
-template <int NP, bool USE_LUT>
+template <int NP, int USE_LUT> // 0: bit fills, 1: the full tables, 2: the small table
 __device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
                                                    uint32_t lb, uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     EqLut t = lut;
-    if (USE_LUT) lut_build<NP>(t, P, 0xFFFFFFFFu);
+    if (USE_LUT == 1) lut_build<NP>(t, P, 0xFFFFFFFFu);
+    if (USE_LUT == 2) mlut_build<NP>(t, P, 0xFFFFFFFFu);
 #if STRSIM_STAGE_PRIO_PLANES
     __builtin_amdgcn_s_setprio(0);
 #endif
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
-    const uint32_t dist = USE_LUT ? lev_myers32_lut<NP>(t, wa, la1, tmin, tmax, P, lb1) : lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    const uint32_t dist = USE_LUT == 1   ? lev_myers32_lut<NP>(t, wa, la1, tmin, tmax, P, lb1)
+                          : USE_LUT == 2 ? lev_myers32_mlut<NP>(t, wa, la1, tmin, tmax, P, lb1)
+                                         : lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
     uint32_t code = dist * (uint32_t)QTAB_N + (la1 > lb1 ? la1 : lb1);
     // both empty: 1.0 = 1 - 0/1; one side empty: 0.0 = 1 - 1/1   (strsim.rs:128, :160)
     if (!live) code = (la == 0u && lb == 0u) ? 1u : (uint32_t)QTAB_N + 1u;
@@ -294,6 +311,7 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
                                               uint32_t last, uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
     constexpr bool LUT = stage_uses_lut<MEASURE>();
+    constexpr int LUTMODE = LUT ? 1 : (stage_uses_mlut<MEASURE>() ? 2 : 0);
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
     // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any high bit leaves
@@ -317,15 +335,15 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
 #if defined(STRSIM_EXP_NOCORE)   // diagnostic builds only: everything but the cores / the cores twice
         code = (la + tmin + tmax + (wide ? 1u : 0u)) * (uint32_t)QTAB_N + lb;
 #else
-        if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
-        else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        if (wide) code = stage_lev_code<7, LUTMODE>(lut, wt, la, wp, lb, tmin, tmax);
+        else code = stage_lev_code<5, LUTMODE>(lut, wt, la, wp, lb, tmin, tmax);
 #if defined(STRSIM_EXP_CORE2X)
         {
             uint32_t wt2[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) wt2[q] = wt[q] ^ (code >> 31);
-            if (wide) code = stage_lev_code<7, LUT>(lut, wt2, la, wp, lb, tmin, tmax);
-            else code = stage_lev_code<5, LUT>(lut, wt2, la, wp, lb, tmin, tmax);
+            if (wide) code = stage_lev_code<7, LUTMODE>(lut, wt2, la, wp, lb, tmin, tmax);
+            else code = stage_lev_code<5, LUTMODE>(lut, wt2, la, wp, lb, tmin, tmax);
         }
 #endif
 #endif
@@ -349,7 +367,7 @@ __device__ __forceinline__ void
 lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs,
              uint64_t n, unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
-             const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
+             const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
@@ -360,10 +378,11 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
-    constexpr bool LUT = stage_uses_lut<MEASURE>();
+    constexpr bool LUT = stage_uses_lut<MEASURE>(), MLUT = stage_uses_mlut<MEASURE>();
     // The 1 KB behind each wave's tables holds 128 of the block's row descriptors (without tables: an array of their own).
     static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
-    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : 16];
+    // (the small table: 1 KB per wave at a 1 KB boundary)
+    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : (MLUT ? MLUT_WAVE_BYTES * STAGE_WAVES : 16)];
     __shared__ uint2 s_desc_own[LUT ? 1 : B];
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
     auto desc_at = [&](uint32_t p) -> uint2 * { // descriptor of position p of the length order
@@ -426,9 +445,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     auto grab = [&](uint32_t seen, uint32_t &lo, uint32_t &sz) { // thread 0 only
         // (64 * 4 * workgroups chunks left or more: the cap; no division on this path)
         const uint32_t left = nchunks32 > seen ? nchunks32 - seen : 0u;
-        uint32_t want = 64u;
-        if (left < 256u * gridDim.x) want = left / (4u * gridDim.x);
-        sz = want < (uint32_t)(B / 64) ? (uint32_t)(B / 64) : want;
+        uint32_t want = (uint32_t)STRSIM_STAGE_RANGE_MAX;
+        if (left < (uint32_t)(STRSIM_STAGE_RANGE_MAX * STRSIM_STAGE_RANGE_DIV) * gridDim.x) want = left / ((uint32_t)STRSIM_STAGE_RANGE_DIV * gridDim.x);
+        sz = want < (uint32_t)(STRSIM_STAGE_RANGE_MIN_BLOCKS * (B / 64)) ? (uint32_t)(STRSIM_STAGE_RANGE_MIN_BLOCKS * (B / 64)) : want;
         lo = __hip_atomic_fetch_add(&sched[0], sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     uint32_t grab_lo = 0u, grab_sz = 0u; // thread 0: the range after the next one, on its way
@@ -451,7 +470,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 
     EqLut lut; // this wave's match-mask tables
     lut.lane4 = lane * 4u;
-    lut.krep = ((STRSIM_LDS_ADDR(&s_lut[0]) >> 8) + 16u * wv) * 0x01010101u;
+    lut.krep = ((STRSIM_LDS_ADDR(&s_lut[0]) >> 8) + (LUT ? 16u : 4u) * wv) * 0x01010101u;
     const uint32_t ldsOffA = STRSIM_LDS_ADDR(&s_off[0][0]), ldsOffB = STRSIM_LDS_ADDR(&s_off[1][0]);
     const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0]);
     const uint32_t wvu = uniform(wv);
@@ -694,6 +713,13 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         STAGE_STAMP(4);
         // ---- D: the bytes have landed (every wave waits for its own DMA, the barrier makes that workgroup-wide)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The column's last 16-byte chunk may reach past the column's last byte: what lies there is not the caller's (pad bytes,
+        // another allocation) and a high bit in it would send the block's last rows to the slow kernels at random.  The lane
+        // that copied that chunk zeroes its tail (its own copy has landed; the barrier publishes the zeros).
+        if (!bcastA && leftA < (chunksA << 4) && tid == ((chunksA - 1u) & (uint32_t)(STAGE_BLOCK - 1)))
+            for (uint32_t b = leftA; b < (chunksA << 4); ++b) s_bytes[b] = 0;
+        if (!bcastB && leftB < (chunksB << 4) && tid == ((chunksB - 1u) & (uint32_t)(STAGE_BLOCK - 1)))
+            for (uint32_t b = leftB; b < (chunksB << 4); ++b) s_bytes[COLB + b] = 0;
         lds_barrier();
         STAGE_STAMP(5);
         if (tid < 32u) s_cnt[tid] = 0u; // read by sortB above, next used by sortA behind barrier G
@@ -764,6 +790,10 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             if (publish) {
                 const uint32_t total = __hip_atomic_load(&sched[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&publish->lane_left, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // a call that consists of this kernel alone (strsim_capi.cpp: no slow rows expected) is complete with it: its
+                // ticket tells the host so (every result store of every workgroup happened before that workgroup's increment
+                // of sched[1], which this thread has acquired)
+                if (ticket) __hip_atomic_store(&publish->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -801,9 +831,9 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(sta
 k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
              unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
-             uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
+             uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish);
+    lane_stage_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }
 
 // The five-output instantiation keeps the matching state of three cores alive at once and stages 64 bits per row.
@@ -811,7 +841,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(sta
 k_lane_stage_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
                  unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
-                 uint32_t *__restrict__ sched, DevStatus *__restrict__ publish)
+                 uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish);
+    lane_stage_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }

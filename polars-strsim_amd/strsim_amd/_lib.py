@@ -125,6 +125,12 @@ def lib():
     L.strsim_ctx_last_wave_rows.argtypes = [vp]
     L.strsim_ctx_last_long_rows.restype = u64
     L.strsim_ctx_last_long_rows.argtypes = [vp]
+    L.strsim_ctx_last_late_rows.restype = u64
+    L.strsim_ctx_last_late_rows.argtypes = [vp]
+    L.strsim_ctx_enqueued_ops.restype = u64
+    L.strsim_ctx_enqueued_ops.argtypes = [vp]
+    L.strsim_ctx_set_stream_ordered.restype = i32
+    L.strsim_ctx_set_stream_ordered.argtypes = [vp, i32]
     _lib = L
     return L
 

@@ -73,6 +73,22 @@ class Context:
         return int(lib().strsim_ctx_last_wave_rows(self._h))
 
     @property
+    def last_late_rows(self):
+        """Rows finished by a pass that the last synchronize() / retire_oldest() launched (slow rows of a one-launch call,
+        long strings): written AFTER whatever was enqueued on the stream behind the call."""
+        return int(lib().strsim_ctx_last_late_rows(self._h))
+
+    @property
+    def enqueued_ops(self):
+        """Kernels + device copies enqueued for pair calls so far (1 per call when no slow rows are expected, else 5)."""
+        return int(lib().strsim_ctx_enqueued_ops(self._h))
+
+    def set_stream_ordered(self, enable=True):
+        """True: every call enqueues all its kernels up front, so results (strings <= 1024 bytes) are complete in stream
+        order -- for callers that consume them behind an event without retiring the call (strsim_ctx_set_stream_ordered)."""
+        check(lib().strsim_ctx_set_stream_ordered(self._h, 1 if enable else 0))
+
+    @property
     def last_long_rows(self):
         """Rows with a string beyond the wave-kernel cap among the calls the last synchronize() retired."""
         return int(lib().strsim_ctx_last_long_rows(self._h))

@@ -67,13 +67,19 @@ extern "C" uint32_t harness_lev_snap(const uint8_t *a, uint32_t la, const uint8_
         build_planes<5>(wb, P);
         lut_build<5>(t, P, 0xFFFFFFFFu);
         const uint32_t d = lev_myers32_snap<5>(wa, la, tmin, tmax, P, lb);
-        return lev_myers32_lut<5>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
+        if (lev_myers32_lut<5>(t, wa, la, tmin, tmax, P, lb) != d) return 0xFFFFFFFFu;
+        EqLut tm{};
+        mlut_build<5>(tm, P, 0xFFFFFFFFu);
+        return lev_myers32_mlut<5>(tm, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFEu;
     }
     uint32_t P[7];
     build_planes<7>(wb, P);
     lut_build<7>(t, P, 0xFFFFFFFFu);
     const uint32_t d = lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
-    return lev_myers32_lut<7>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
+    if (lev_myers32_lut<7>(t, wa, la, tmin, tmax, P, lb) != d) return 0xFFFFFFFFu;
+    EqLut tm{};
+    mlut_build<7>(tm, P, 0xFFFFFFFFu);
+    return lev_myers32_mlut<7>(tm, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFEu;
 }
 
 // the one-loop cores (lane_cores32) with all three cores on, and each of them on its own: out[0..3] = dist, m, t, isect of

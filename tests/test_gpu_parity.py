@@ -499,3 +499,91 @@ def test_default_stream_handle_is_refused(S):
     """Handle 0 would silently become an own stream inside the C ABI (NULL = create one): the Python layer says so instead."""
     with pytest.raises(ValueError, match="default stream"):
         S.Context(0, stream=0)
+
+
+def _mixed_frame(S, slow):
+    """30 000 short ASCII rows + `slow` rows for the kernels behind the lane kernel (33..128 bytes, non-ASCII, long)."""
+    import torch
+    A, B = gen.pairs(901, 30_000, gen.ASCII_LOWER, 0, 32, max_bytes=32)
+    if slow:
+        A2, B2 = gen.pairs(902, slow, gen.ASCII_LOWER, 40, 120)
+        A3, B3 = gen.pairs(903, max(slow // 4, 1), gen.MIXED, 0, 60)
+        pos = len(A) // 3
+        A, B = A[:pos] + A2 + A3 + A[pos:], B[:pos] + B2 + B3 + B[pos:]
+    oa, va = S.pack_strings(A)
+    ob, vb = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    cols = (t(oa, np.int32), t(np.concatenate([va, pad]), np.uint8), t(ob, np.int32), t(np.concatenate([vb, pad]), np.uint8))
+    torch.cuda.synchronize()
+    return A, B, cols
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_one_launch_calls_and_deferred_slow_rows(S, measure):
+    """A call on a context whose last call left no slow rows is ONE launch; if it does hold slow rows they are finished when
+    the call is retired (last_late_rows says so) and the following calls enqueue all five operations up front again; a clean
+    call brings the context back to one launch.  Frames with 0, 1 and many slow rows, every result against the oracle."""
+    frames = {k: _mixed_frame(S, k) for k in (0, 1, 700)}
+    exp = {k: O.batch_strings(measure, f[0], f[1], 8) for k, f in frames.items()}
+    with S.Context(0) as ctx:
+        def call(k):
+            before = ctx.enqueued_ops
+            out = ctx.pairs_device(measure, *frames[k][2])
+            ops = ctx.enqueued_ops - before
+            ctx.synchronize()
+            assert_bit_exact(out.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "%s, %d slow rows" % (measure, k))
+            return ops, ctx.last_late_rows
+        assert call(0) == (1, 0)                    # a fresh context expects no slow rows: one launch, nothing late
+        ops, late = call(1)                         # ... wrongly, this time: the slow row is finished at synchronize()
+        assert ops == 1 and late >= 1
+        assert call(700) == (5, 0)                  # now the whole chain goes up front
+        assert call(0) == (5, 0)                    # (the prediction follows the call retired LAST)
+        assert call(0) == (1, 0)
+        ops, late = call(700)
+        assert ops == 1 and late >= 700
+        # several mispredicted calls in flight at once (more than the context has mask buffers), retired by one synchronize()
+        ctx.pairs_device(measure, *frames[0][2])
+        ctx.synchronize()
+        outs = [ctx.pairs_device(measure, *frames[k][2]) for k in (700, 1, 700, 0, 700, 1, 700)]
+        ctx.synchronize()
+        for o, k in zip(outs, (700, 1, 700, 0, 700, 1, 700)):
+            assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "%s, in flight, %d slow rows" % (measure, k))
+
+
+def test_fused_call_is_one_launch_without_slow_rows(S):
+    A, B, cols = _mixed_frame(S, 0)
+    A2, B2, cols2 = _mixed_frame(S, 50)
+    with S.Context(0) as ctx:
+        before = ctx.enqueued_ops
+        outs = ctx.pairs_device_all(*cols)
+        assert ctx.enqueued_ops - before == 1
+        ctx.synchronize()
+        for m, o in zip(S.MEASURES, outs):
+            assert_bit_exact(o.cpu().numpy(), O.batch_strings(m, A, B, 8), A, B, "fused, one launch, " + m)
+        outs = ctx.pairs_device_all(*cols2)  # mispredicted: the slow rows of all five measures at synchronize()
+        assert ctx.enqueued_ops - before == 2
+        ctx.synchronize()
+        assert ctx.last_late_rows >= 50
+        for m, o in zip(S.MEASURES, outs):
+            assert_bit_exact(o.cpu().numpy(), O.batch_strings(m, A2, B2, 8), A2, B2, "fused, deferred, " + m)
+
+
+def test_stream_ordered_context_completes_in_stream_order(S):
+    """set_stream_ordered(True): the results of a frame WITH slow rows are complete for work enqueued behind the call on the
+    context's stream -- no retire in between (what bench.py's gather and any torch consumer on that stream rely on)."""
+    import torch
+    A, B, cols = _mixed_frame(S, 300)
+    exp = O.batch_strings("jaro_winkler", A, B, 8)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), S.Context(0, stream=s.cuda_stream) as ctx:
+        ctx.set_stream_ordered(True)
+        before = ctx.enqueued_ops
+        out = ctx.pairs_device("jaro_winkler", *cols)
+        assert ctx.enqueued_ops - before == 5
+        got = out.cpu().numpy()  # a copy on s, behind the kernels
+        assert_bit_exact(got, exp, A, B, "stream-ordered")
+        ctx.synchronize()
+        assert ctx.last_late_rows == 0
+    torch.cuda.synchronize()
