@@ -12,17 +12,15 @@ import numpy as np
 import pyarrow as pa
 
 from bench_support import workload as W
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from strsim_amd import arrow_host as H
+import pack_harness
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 oa, va, _, _ = W.host_columns(2, W.UNIFORM, 1, 32, 0, n)
 a = pa.StringArray.from_buffers(n, pa.py_buffer(oa.astype(np.int32)), pa.py_buffer(va)).cast(pa.string_view())
-L = H._load()
-fn = L._strsim_test_pack_series
-fn.restype = C.c_int
-fn.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
-               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_uint]
+fn = pack_harness.lib()._strsim_test_pack_series
 chunks, dtype = H._chunks(a, "vu")
 off = np.zeros(n + 1, dtype=np.uint32)
 val = np.zeros(len(va) + 64 * 1024, dtype=np.uint8)

@@ -98,12 +98,6 @@ POLARS_PLUGIN_DECLARE(jaro_winkler)
 POLARS_PLUGIN_DECLARE(jaccard)
 POLARS_PLUGIN_DECLARE(sorensen_dice)
 
-/* Test hook, not part of the Polars contract: the plugin's host-side packing of one Series (rows [r0, r1)) into
- * caller buffers, without touching the GPU.  See csrc/polars_plugin.cpp. */
-POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0, uint64_t r1, uint32_t *off_out,
-                                               uint8_t *val_out, uint64_t val_cap, uint64_t *rows_out, uint64_t *bytes_out,
-                                               uint8_t *valid_out, unsigned threads);
-
 #ifdef __cplusplus
 }
 #endif

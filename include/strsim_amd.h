@@ -88,6 +88,14 @@ STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
  * Nulls are not seen here: like the reference's arity helpers the kernels compute on the bytes under
  * every slot; validity is combined by the caller (the plugin layer does it).
  *
+ * Reads beyond the strings: the kernels copy the values of a block of rows in whole 16-byte chunks, from the
+ * 16-byte-aligned address at or below the block's first byte (a_values + a_offsets[first row]) up to the chunk that
+ * holds the column's last byte (a_values + a_offsets[a_rows]) -- up to 15 bytes in front of and behind the bytes the
+ * offsets describe.  Those reads stay inside the 16-byte-aligned chunks the column itself touches (so inside its
+ * pages); bytes in front belong to whatever precedes the column in the caller's buffer and only ever sit beside a
+ * string in a staging area, bytes behind the column's last byte are replaced by zeros before any row looks at them.
+ * Nothing outside [a_offsets[0], a_offsets[a_rows]) can change a result.
+ *
  * The call is asynchronous: it returns once the kernels are enqueued on the context's stream.
  * Results are complete after strsim_ctx_synchronize() (or strsim_ctx_retire_oldest() of this call).
  * All buffers of a call must stay valid until then.
@@ -163,7 +171,9 @@ STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms,
  * (lengths: `rows` bytes on the device, 16-byte aligned; offsets: rows + 1 words).  Asynchronous on the context's stream.
  * For a host that holds strings as views / (pointer, length) pairs (Polars' Utf8View, the layout the reference iterates at
  * strsim.rs:46-47) and ships one length byte per row over PCIe instead of a u32 offset; strings of at most 255 bytes, at
- * most 2^26 rows per call.  The result is what strsim_pairs_device() takes as a_offsets / b_offsets. */
+ * most STRSIM_OFFSETS_FROM_LENGTHS_MAX_ROWS rows per call (= floor((2^32 - 1) / 255): the 32-bit offsets cannot wrap whatever
+ * the lengths are; more rows: STRSIM_ERR_ARG).  The result is what strsim_pairs_device() takes as a_offsets / b_offsets. */
+#define STRSIM_OFFSETS_FROM_LENGTHS_MAX_ROWS 16843009u
 STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets);
 
 /* For a caller that keeps several calls in flight on the context's stream and learns of their completion by its own means

@@ -516,38 +516,33 @@ struct Slot {
     }
 };
 
-// ---- device context per calling thread (Polars may call from several of its threads at once) -------
-struct ThreadCtx {
+// ---- device pipelines per calling thread (Polars may call from several of its threads at once) -----
+// One pipeline = one device context + its stream, a copy stream for the results, three slots and the literal's buffers.  A
+// calling thread keeps one pipeline per entry of the device list (an ordinal may repeat: two pipelines on one GPU).
+struct Pipe {
     strsim_ctx_t *ctx = nullptr;
     int device = 0;
     Slot slot[3];             // two slices in flight on the GPU + the one being packed
     hipStream_t d2h = nullptr; // results travel back on their own stream: D2H of slice k runs beside H2D of slice k+1
     Buf lit_off, lit_val;     // device copy of a literal side
     Buf lit_h_off, lit_h_val; // its pinned host staging
-    ~ThreadCtx()
+    void close()
     {
-        if (ctx) {
-            (void)hipSetDevice(device);
-            if (d2h) (void)hipStreamDestroy(d2h);
-            for (auto &s : slot) s.release();
-            lit_off.release(); lit_val.release();
-            lit_h_off.release(); lit_h_val.release();
-            strsim_ctx_destroy(ctx);
-        }
+        if (!ctx) return;
+        (void)hipSetDevice(device);
+        if (d2h) (void)hipStreamDestroy(d2h);
+        d2h = nullptr;
+        for (auto &s : slot) s.release();
+        lit_off.release(); lit_val.release();
+        lit_h_off.release(); lit_h_val.release();
+        strsim_ctx_destroy(ctx);
+        ctx = nullptr;
     }
-    // the context of this thread on device `dev` (a thread that is asked for another device than last time starts over)
-    strsim_ctx_t *get(int dev)
+    ~Pipe() { close(); }
+    // this pipeline on device `dev` (a pipeline that is asked for another device than last time starts over)
+    strsim_ctx_t *open(int dev)
     {
-        if (ctx && dev != device) {
-            (void)hipSetDevice(device);
-            if (d2h) (void)hipStreamDestroy(d2h);
-            d2h = nullptr;
-            for (auto &s : slot) s.release();
-            lit_off.release(); lit_val.release();
-            lit_h_off.release(); lit_h_val.release();
-            strsim_ctx_destroy(ctx);
-            ctx = nullptr;
-        }
+        if (ctx && dev != device) close();
         if (!ctx) {
             device = dev;
             if (strsim_ctx_create(device, nullptr, &ctx) != STRSIM_OK) fail(strsim_last_error_message());
@@ -558,37 +553,50 @@ struct ThreadCtx {
         return ctx;
     }
 };
-thread_local ThreadCtx g_ctx;
+struct ThreadPipes {
+    std::vector<Pipe *> p;
+    Pipe &at(size_t i) { while (p.size() <= i) p.push_back(new Pipe); return *p[i]; }
+    ~ThreadPipes() { for (Pipe *q : p) delete q; }
+};
+thread_local ThreadPipes g_pipes;
 
-// The devices a call may use: POLARS_STRSIM_DEVICES = comma-separated ordinals (an ordinal may repeat: two pipelines on one
-// GPU, which is how the sharding is tested on a one-GPU box), else POLARS_STRSIM_DEVICE = one ordinal, else every visible GPU.
+// The devices a call uses.  Default: ONE device -- the calling thread's current HIP device (0 unless the host process chose
+// another; one process per GPU under a launcher keeps every process on its own).  POLARS_STRSIM_DEVICE = one ordinal.
+// POLARS_STRSIM_DEVICES = comma-separated ordinals, or "all": a call of several million rows deals its slices out over these
+// devices in turn (an ordinal may repeat: two pipelines on one GPU, which is how this is tested on a one-GPU box).  Opt-in,
+// because every pipeline pins staging memory on its device's behalf for as long as the calling thread lives.
 std::vector<int> plugin_devices()
 {
     std::vector<int> v;
     if (const char *e = getenv("POLARS_STRSIM_DEVICES")) {
-        for (const char *p = e; *p;) {
-            char *end = nullptr;
-            const long d = strtol(p, &end, 10);
-            if (end == p) break;
-            v.push_back((int)d);
-            p = *end == ',' ? end + 1 : end;
+        if (strcmp(e, "all") == 0) {
+            const int n = strsim_device_count();
+            for (int d = 0; d < n; ++d) v.push_back(d);
+        } else {
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                v.push_back((int)d);
+                p = *end == ',' ? end + 1 : end;
+            }
         }
     } else if (const char *e1 = getenv("POLARS_STRSIM_DEVICE")) {
         v.push_back(atoi(e1));
     } else {
-        const int n = strsim_device_count();
-        for (int d = 0; d < n; ++d) v.push_back(d);
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+        v.push_back(cur);
     }
     if (v.empty()) v.push_back(0); // (no device at all: strsim_ctx_create reports it -- there is no CPU path)
     return v;
 }
-// rows below which a call is not split any further: a shard should at least fill one pipeline slice
+// rows below which a call does not take another device: a device should at least get one full pipeline slice
 uint64_t min_rows_per_device()
 {
     const char *e = getenv("POLARS_STRSIM_MIN_ROWS_PER_DEVICE");
     return e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : (uint64_t)(2u << 20);
 }
-thread_local ForkJoinPool g_devpool; // one long-lived host thread per extra device (their thread-local contexts persist)
 
 // Small calls: up to this many rows (and direct_bytes() packed bytes per column) the kernels read the pinned staging and write
 // the pinned result buffer through the device's mapping of host memory.  The bytes cross PCIe from inside the kernels
@@ -709,7 +717,7 @@ bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, boo
 
 struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin call on stderr
     bool on;
-    double t_pack = 0, t_wait = 0, t_d2h = 0, t_copy = 0, t_launch = 0;
+    double t_pack = 0, t_copy = 0;
     std::chrono::steady_clock::time_point t0;
     PhaseTimer() : on(getenv("POLARS_STRSIM_TRACE") != nullptr) {}
     void start() { if (on) t0 = std::chrono::steady_clock::now(); }
@@ -725,42 +733,58 @@ uint64_t env_rows(const char *name, uint64_t dflt)
     return v ? (uint64_t)v : dflt;
 }
 
-// One device's share of a call: rows [lo, hi) of the output through this thread's context on `device` (a two-slot pipeline:
-// pack slice k+1 on the host while the GPU has slice k), results straight into out[lo .. hi) -- by the copy engine itself when
-// the output column is pinned memory (out_pinned), else through the slot's pinned result buffer and a host copy.
-void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t lo, uint64_t hi, double *out, bool out_pinned,
-               unsigned T, bool direct_call, int device, PhaseTimer &tm)
-{
-    strsim_ctx_t *ctx = g_ctx.get(device);
-    hipStream_t stream = static_cast<hipStream_t>(strsim_ctx_stream(ctx));
+struct PipeTimes { double t_launch = 0, t_wait = 0, t_d2h = 0; unsigned slices = 0; };
 
-    // a literal side is packed and shipped once
-    const uint32_t *lit_off_d = nullptr;
-    const uint8_t *lit_val_d = nullptr;
+// Rows [0, n) of a call through the pipelines of `devs`: slices are packed one after the other by the calling thread's packing
+// pool -- ALL of its threads on every slice -- and dealt out to the pipelines in turn: slice i goes to pipeline i % D, into
+// slot (i / D) % 3 of it, is launched there (H2D + kernels on the pipeline's stream, the D2H of its results on the
+// pipeline's copy stream, over that device's own PCIe link) and is finished two rounds later, when slice i + 2 D has been
+// launched: two slices in flight per device while the host packs the next.  Results go straight into out[] -- by the copy
+// engine itself when the output column is pinned memory (out_pinned), else through the slot's pinned result buffer and a
+// host copy.  (Reference: the row fan-out of strsim.rs:72-100; here the host has ONE packer, so the devices take turns
+// instead of shards -- a device's share of the packing threads would be a fraction of them.)
+void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t n, double *out, bool out_pinned, unsigned T,
+              bool direct_call, const std::vector<int> &devs, PhaseTimer &tm, std::vector<PipeTimes> &ptimes)
+{
+    const size_t D = devs.size();
+    ptimes.assign(D, PipeTimes{});
+    std::vector<Pipe *> pipes(D);
+    std::vector<hipStream_t> streams(D);
+    for (size_t d = 0; d < D; ++d) {
+        pipes[d] = &g_pipes.at(d);
+        streams[d] = static_cast<hipStream_t>(strsim_ctx_stream(pipes[d]->open(devs[d])));
+    }
+
+    // a literal side is packed once and shipped to every pipeline
+    std::vector<const uint32_t *> lit_off_d(D, nullptr);
+    std::vector<const uint8_t *> lit_val_d(D, nullptr);
     for (int s = 0; s < 2; ++s) {
         if (!lit[s]) continue;
-        Buf &ho = g_ctx.lit_h_off, &hv = g_ctx.lit_h_val; // persistent pinned staging: the call is synchronous,
-        const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
-        if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
-        if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
-            lit_off_d = static_cast<const uint32_t *>(mapped(ho.p));
-            lit_val_d = static_cast<const uint8_t *>(mapped(hv.p));
-            continue;
+        for (size_t d = 0; d < D; ++d) {
+            Pipe &P = *pipes[d];
+            HIP_OR_FAIL(hipSetDevice(P.device));
+            Buf &ho = P.lit_h_off, &hv = P.lit_h_val; // persistent pinned staging: the call is synchronous,
+            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
+            if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
+            if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
+                lit_off_d[d] = static_cast<const uint32_t *>(mapped(ho.p));
+                lit_val_d[d] = static_cast<const uint8_t *>(mapped(hv.p));
+                continue;
+            }
+            P.lit_off.reserve(2 * sizeof(uint32_t));
+            P.lit_val.reserve(bytes + 64);
+            HIP_OR_FAIL(hipMemcpyAsync(P.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, streams[d]));
+            if (bytes) HIP_OR_FAIL(hipMemcpyAsync(P.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, streams[d]));
+            lit_off_d[d] = static_cast<const uint32_t *>(P.lit_off.p);
+            lit_val_d[d] = static_cast<const uint8_t *>(P.lit_val.p);
         }
-        g_ctx.lit_off.reserve(2 * sizeof(uint32_t));
-        g_ctx.lit_val.reserve(bytes + 64);
-        HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        if (bytes) HIP_OR_FAIL(hipMemcpyAsync(g_ctx.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, stream));
-        lit_off_d = static_cast<const uint32_t *>(g_ctx.lit_off.p);
-        lit_val_d = static_cast<const uint8_t *>(g_ctx.lit_val.p);
     }
 
     // (slices computed in place read their offsets from the pinned staging; POLARS_STRSIM_LENGTH_BYTES=0: always ship offsets)
     const char *lens8_env = getenv("POLARS_STRSIM_LENGTH_BYTES");
     const bool lens8_ok = !(lens8_env && atoi(lens8_env) == 0) && !direct_call;
-    // Software pipeline over row slices: pack(k+1) on the host overlaps H2D(k) + kernels(k) on the GPU.
     auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
-        uint64_t rows = std::min<uint64_t>(want, hi - r0);
+        uint64_t rows = std::min<uint64_t>(want, n - r0);
         for (;;) {
             bool fits = true;
             sl.lens8[0] = sl.lens8[1] = false;
@@ -780,7 +804,11 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         sl.r0 = r0; sl.rows = rows;
         return rows;
     };
-    auto launch = [&](Slot &sl) {
+    auto launch = [&](size_t d, Slot &sl) {
+        Pipe &P = *pipes[d];
+        strsim_ctx_t *ctx = P.ctx;
+        hipStream_t stream = streams[d];
+        HIP_OR_FAIL(hipSetDevice(P.device));
         const uint32_t *doff[2];
         const uint8_t *dval[2];
         uint64_t drows[2];
@@ -788,7 +816,7 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         for (int s = 0; s < 2; ++s)
             if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
         for (int s = 0; s < 2; ++s) {
-            if (lit[s]) { doff[s] = lit_off_d; dval[s] = lit_val_d; drows[s] = 1; continue; }
+            if (lit[s]) { doff[s] = lit_off_d[d]; dval[s] = lit_val_d[d]; drows[s] = 1; continue; }
             drows[s] = sl.rows;
             if (sl.direct) {
                 doff[s] = static_cast<const uint32_t *>(mapped(sl.h_off[s].p));
@@ -821,30 +849,34 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
             if (!sl.ev_kernels) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_kernels, hipEventDisableTiming));
             if (!sl.ev_results) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_results, hipEventDisableTiming));
             HIP_OR_FAIL(hipEventRecord(sl.ev_kernels, stream));
-            HIP_OR_FAIL(hipStreamWaitEvent(g_ctx.d2h, sl.ev_kernels, 0));
+            HIP_OR_FAIL(hipStreamWaitEvent(P.d2h, sl.ev_kernels, 0));
             HIP_OR_FAIL(hipMemcpyAsync(out_pinned ? static_cast<void *>(out + sl.r0) : sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double),
-                                       hipMemcpyDeviceToHost, g_ctx.d2h));
-            HIP_OR_FAIL(hipEventRecord(sl.ev_results, g_ctx.d2h));
+                                       hipMemcpyDeviceToHost, P.d2h));
+            HIP_OR_FAIL(hipEventRecord(sl.ev_results, P.d2h));
         }
     };
     // the slice's results have arrived (in the output column, or in the slot's pinned buffer): retire the call; copy if needed
-    auto finish = [&](Slot &sl) {
-        tm.start();
+    auto finish = [&](size_t d, Slot &sl) {
+        Pipe &P = *pipes[d];
+        strsim_ctx_t *ctx = P.ctx;
+        PhaseTimer t1 = tm; // (same switch, own clock)
+        HIP_OR_FAIL(hipSetDevice(P.device));
+        t1.start();
         if (sl.direct) {
             if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message());
         } else {
             HIP_OR_FAIL(hipEventSynchronize(sl.ev_results));
-            // (the oldest call in flight is this slice's: slices are launched and finished in order)
+            // (the oldest call in flight on this pipeline is this slice's: slices are launched and finished in order)
             if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the deferred slow-row and long-string passes
         }
-        tm.stop(tm.t_wait);
+        t1.stop(ptimes[d].t_wait);
         const bool via_slot = sl.direct || !out_pinned;
         if (strsim_ctx_last_late_rows(ctx) != 0 && !sl.direct) { // rows finished by a pass launched just now: fetch the column again
-            tm.start();
+            t1.start();
             HIP_OR_FAIL(hipMemcpyAsync(via_slot ? sl.h_out.p : static_cast<void *>(out + sl.r0), sl.d_out.p, sl.rows * sizeof(double),
-                                       hipMemcpyDeviceToHost, stream));
-            HIP_OR_FAIL(hipStreamSynchronize(stream));
-            tm.stop(tm.t_d2h);
+                                       hipMemcpyDeviceToHost, streams[d]));
+            HIP_OR_FAIL(hipStreamSynchronize(streams[d]));
+            t1.stop(ptimes[d].t_d2h);
         }
         if (!via_slot) return;
         tm.start();
@@ -857,21 +889,21 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
         tm.stop(tm.t_copy);
     };
 
-    // Three slots: two slices in flight on the GPU (H2D + kernels of slice k+1 on the compute stream beside the D2H of slice
-    // k on the copy stream) while the host packs slice k+2.  PCIe carries 41 B in and 8 B out per pair in the two directions at once, the host
-    // touches every byte once (pack) -- per 2 M-row slice 1.45 ms of link against 1.3 ms of packing.  Slices ramp up from
-    // RAMP_ROWS and down again at the end, so that neither the first pack nor the last slice's trip is exposed at full size.
+    // Slices ramp up from RAMP_ROWS and down again at the end, so that neither the first pack nor the last slice's trip is
+    // exposed at full size.  PCIe carries 35-41 B in and 8 B out per pair in the two directions at once, the host touches every
+    // byte once (pack) -- per 2 M-row slice 1.45 ms of link against 1.3 ms of packing.
+    // (knobs read per call: four getenv; tests shrink them to cut a small frame into many slices)
     // (in round 1 cutting a 1 M-row call into four slices lost -- four small packs cost 1.3 ms instead of 0.6 ms; with both columns
     // in one job and a pool that spins between jobs it wins, so only calls up to SINGLE_ROWS stay in one piece)
-    static const uint64_t RAMP_ROWS = env_rows("POLARS_STRSIM_RAMP_ROWS", 512u << 10);   // first slice (tuning knobs)
-    static const uint64_t FULL_ROWS = env_rows("POLARS_STRSIM_SLICE_ROWS", SLICE_ROWS);   // steady-state slice
-    static const uint64_t GROW_PCT = env_rows("POLARS_STRSIM_RAMP_GROW_PCT", 150);         // slice k+1 = slice k x this / 100
-    static const uint64_t SINGLE_ROWS = env_rows("POLARS_STRSIM_SINGLE_SLICE_ROWS", 300000); // calls up to here are not cut (1 M rows in four slices: 2.39 -> 2.06 ms)
+    const uint64_t RAMP_ROWS = env_rows("POLARS_STRSIM_RAMP_ROWS", 512u << 10);   // first slice (tuning knobs)
+    const uint64_t FULL_ROWS = env_rows("POLARS_STRSIM_SLICE_ROWS", SLICE_ROWS);   // steady-state slice
+    const uint64_t GROW_PCT = env_rows("POLARS_STRSIM_RAMP_GROW_PCT", 150);         // slice k+1 = slice k x this / 100
+    const uint64_t SINGLE_ROWS = env_rows("POLARS_STRSIM_SINGLE_SLICE_ROWS", 300000); // calls up to here are not cut (1 M rows in four slices: 2.39 -> 2.06 ms)
     uint64_t prev_rows = 0;
     auto next_rows = [&](uint64_t r0) -> uint64_t {
-        const uint64_t left = hi - r0;
-        if (direct_call || hi - lo <= SINGLE_ROWS) return left;     // small calls: one slice
-        const uint64_t ramp = hi - lo <= (2u << 20) ? RAMP_ROWS / 2 : RAMP_ROWS; // a mid-size call starts (and stays) smaller
+        const uint64_t left = n - r0;
+        if (direct_call || n <= SINGLE_ROWS) return left;     // small calls: one slice
+        const uint64_t ramp = n <= (2u << 20) ? RAMP_ROWS / 2 : RAMP_ROWS; // a mid-size call starts (and stays) smaller
         uint64_t want = prev_rows == 0 ? ramp : std::min<uint64_t>(FULL_ROWS, prev_rows * GROW_PCT / 100);
         want = std::min<uint64_t>(want, SLICE_ROWS);
         if (left < 2 * want) want = std::max<uint64_t>(ramp, ((left / 2 + 65535) >> 16) << 16); // taper
@@ -882,22 +914,112 @@ void run_shard(int measure, const Column (&col)[2], const bool (&lit)[2], uint64
     // whatever goes wrong below (a failed launch, a string beyond 4 GiB in a later slice): nothing of this call may still be in
     // flight when the error leaves the plugin -- the slots are reused by the next call and the output column is released
     struct Drain {
-        strsim_ctx_t *ctx; hipStream_t d2h; bool armed = true;
-        ~Drain() { if (armed) { (void)strsim_ctx_synchronize(ctx); (void)hipStreamSynchronize(d2h); } }
-    } drain{ctx, g_ctx.d2h};
-    uint64_t r0 = lo;
-    unsigned k = 0;
-    tm.start(); r0 += pack(g_ctx.slot[0], r0, next_rows(r0)); tm.stop(tm.t_pack);
-    tm.start(); launch(g_ctx.slot[0]); tm.stop(tm.t_launch);
-    while (r0 < hi) {
-        Slot &nxt = g_ctx.slot[(k + 1) % 3];
-        tm.start(); r0 += pack(nxt, r0, next_rows(r0)); tm.stop(tm.t_pack); // overlaps the GPU work of slices k-1, k
-        tm.start(); launch(nxt); tm.stop(tm.t_launch);
-        finish(g_ctx.slot[k % 3]);
-        ++k;
+        std::vector<Pipe *> &pipes; bool armed = true;
+        ~Drain()
+        {
+            if (!armed) return;
+            for (Pipe *P : pipes) { (void)hipSetDevice(P->device); (void)strsim_ctx_synchronize(P->ctx); (void)hipStreamSynchronize(P->d2h); }
+        }
+    } drain{pipes};
+    uint64_t r0 = 0, launched = 0, finished = 0; // slices: i -> pipeline i % D, slot (i / D) % 3
+    auto slot_of = [&](uint64_t i) -> Slot & { return pipes[i % D]->slot[(i / D) % 3]; };
+    while (r0 < n) {
+        Slot &sl = slot_of(launched);
+        tm.start(); r0 += pack(sl, r0, next_rows(r0)); tm.stop(tm.t_pack); // overlaps the GPU work of the slices in flight
+        PhaseTimer t1 = tm;
+        t1.start(); launch(launched % D, sl); t1.stop(ptimes[launched % D].t_launch);
+        ++ptimes[launched % D].slices;
+        ++launched;
+        if (launched - finished > 2 * D) { finish(finished % D, slot_of(finished)); ++finished; } // two in flight per pipeline
     }
-    finish(g_ctx.slot[k % 3]);
+    for (; finished < launched; ++finished) finish(finished % D, slot_of(finished));
     drain.armed = false;
+}
+
+// ---- output validity: AND of the input validities, built word by word on the packing pool ---------------------------
+// bits [bit0, bit0 + n) of `src` (LSB-first, Arrow) as 64-bit words of a stream that starts at bit 0: word k = bits
+// [64 k, 64 k + 64) of the range; bits past the range read as ones
+inline uint64_t bits_word(const uint8_t *src, int64_t bit0, uint64_t n, uint64_t k)
+{
+    const uint64_t first = 64 * k;
+    if (first >= n) return ~0ull;
+    const uint64_t take = std::min<uint64_t>(64, n - first);
+    const int64_t b = bit0 + (int64_t)first;
+    const uint8_t *p = src + (b >> 3);
+    const unsigned sh = (unsigned)(b & 7);
+    uint64_t w = 0;
+    const unsigned nbytes = (unsigned)((sh + take + 7) >> 3); // <= 9
+    for (unsigned q = 0; q < nbytes && q < 8; ++q) w |= (uint64_t)p[q] << (8 * q);
+    w >>= sh;
+    if (nbytes == 9) w |= (uint64_t)p[8] << (64 - sh);
+    if (take < 64) w |= ~0ull << take;
+    return w;
+}
+
+// AND the validity of rows [r0, r1) of `c` into dst, whose bit 0 is row r0 (r0 a multiple of 64): whole words only
+void and_validity(const Column &c, uint64_t r0, uint64_t r1, uint64_t *dst)
+{
+    if (!c.any_null || r0 >= r1) return;
+    for (size_t ci = chunk_of(c, r0); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        if (!k.nulls) continue;
+        const uint64_t lo = std::max(r0, k.row0), hi = std::min(r1, k.row0 + (uint64_t)k.a->length); // rows of this chunk in range
+        // destination words that hold rows [lo, hi): the chunk's bits arrive shifted by (lo - r0) & 63
+        const uint64_t dbit = lo - r0;
+        const int64_t sbit = k.a->offset + (int64_t)(lo - k.row0);
+        const uint64_t cnt = hi - lo;
+        // head: up to the next destination word boundary, then whole source words, shifted in
+        uint64_t done = 0;
+        while (done < cnt) {
+            const uint64_t db = dbit + done;
+            const unsigned dsh = (unsigned)(db & 63);
+            const uint64_t take = std::min<uint64_t>(64 - dsh, cnt - done);
+            uint64_t w = bits_word(k.nulls, sbit + (int64_t)done, take, 0); // ones beyond `take`
+            // place at dsh; ones elsewhere
+            const uint64_t placed = (w << dsh) | (dsh ? (~0ull >> (64 - dsh)) : 0ull);
+            dst[db >> 6] &= placed;
+            done += take;
+        }
+    }
+}
+
+// validity words of rows [0, n) = AND of the non-literal inputs' validities, 64 rows at a time on `T` packing threads (their row
+// ranges are cut at multiples of 64, so no two threads share a word); bits past row n are zero.  The value under a null slot is
+// set to 0.0 in `out` (never observable; keeps the column deterministic).  Returns the null count.
+int64_t build_validity(const Column (&col)[2], const bool (&lit)[2], uint64_t n, bool all_null, unsigned T, uint64_t *vw, double *out)
+{
+    const uint64_t nwords = (n + 63) / 64;
+    if (all_null) {
+        memset(vw, 0, nwords * 8);
+        return (int64_t)n;
+    }
+    const unsigned Tv = (unsigned)std::min<uint64_t>(std::max(1u, T), std::max<uint64_t>(nwords / 4096, 1));
+    std::vector<int64_t> nulls(Tv, 0);
+    fork_join(Tv, [&](unsigned t) {
+        const uint64_t w0 = nwords * t / Tv, w1 = nwords * (t + 1) / Tv;
+        const uint64_t r0 = w0 * 64, r1 = std::min<uint64_t>(w1 * 64, n);
+        for (uint64_t w = w0; w < w1; ++w) vw[w] = ~0ull;
+        for (int s = 0; s < 2; ++s)
+            if (!lit[s]) and_validity(col[s], r0, r1, vw + w0);
+        int64_t cnt = 0;
+        for (uint64_t w = w0; w < w1; ++w) {
+            uint64_t word = vw[w];
+            if (w == nwords - 1 && (n & 63)) word &= ~0ull >> (64 - (n & 63)); // (bits past the column: zero)
+            vw[w] = word;
+            uint64_t zeros = ~word;
+            if (w == nwords - 1 && (n & 63)) zeros &= ~0ull >> (64 - (n & 63));
+            cnt += __builtin_popcountll(zeros);
+            if (out)
+                while (zeros) {
+                    out[w * 64 + (uint64_t)__builtin_ctzll(zeros)] = 0.0;
+                    zeros &= zeros - 1;
+                }
+        }
+        nulls[t] = cnt;
+    });
+    int64_t total = 0;
+    for (int64_t c : nulls) total += c;
+    return total;
 }
 
 void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, bool engine_parallel)
@@ -928,50 +1050,21 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     // a NULL literal: the reference unwrap()s and panics (strsim.rs:62,65,87,90); here every row is null
     const bool all_null = (lit[0] && !row_valid(a, 0)) || (lit[1] && !row_valid(b, 0));
 
+    const unsigned T = pack_threads(engine_parallel, n);
+    std::vector<PipeTimes> ptimes;
+    std::vector<int> devs = plugin_devices();
     if (n != 0 && !all_null) {
-        // Rows shard over the GPUs the way the reference shards them over its threads (strsim.rs:72-100): contiguous ranges by
-        // split_offsets(n, devices) (strsim.rs:21-39), one pipeline per device on its own host thread, each shipping its
-        // slices over its own PCIe link and copying its results into its part of the output -- no collective in one process.
-        const std::vector<int> devs = plugin_devices();
         const bool direct_call = n <= direct_rows();
         const uint64_t D = std::max<uint64_t>(1, std::min<uint64_t>(devs.size(), n / min_rows_per_device()));
-        const unsigned T = std::max(1u, pack_threads(engine_parallel, n) / (unsigned)D);
-        if (D == 1) {
-            run_shard(measure, col, lit, 0, n, out, out_pinned, T, direct_call, devs[0], tm);
-        } else {
-            std::vector<uint64_t> parts(2 * D);
-            strsim_split_offsets(n, D, parts.data());
-            std::vector<PhaseTimer> tms(D);
-            g_devpool.run((unsigned)D, [&](unsigned d) {
-                run_shard(measure, col, lit, parts[2 * d], parts[2 * d] + parts[2 * d + 1], out, out_pinned, T, false, devs[d], tms[d]);
-            });
-            for (const PhaseTimer &t : tms) { // (phase times of the shards ran concurrently: the longest of each is what the call saw)
-                tm.t_pack = std::max(tm.t_pack, t.t_pack); tm.t_wait = std::max(tm.t_wait, t.t_wait);
-                tm.t_d2h = std::max(tm.t_d2h, t.t_d2h); tm.t_copy = std::max(tm.t_copy, t.t_copy);
-                tm.t_launch = std::max(tm.t_launch, t.t_launch);
-            }
-        }
+        devs.resize((size_t)D);
+        run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, devs, tm, ptimes);
     }
 
-    // output validity = AND of the input validities (broadcast for a literal)
+    // output validity = AND of the input validities (broadcast for a literal; a null literal is the all_null case)
     const bool need_validity = all_null || a.any_null || b.any_null;
     if (need_validity && n != 0) {
-        validity = static_cast<uint8_t *>(alloc64((n + 7) / 8));
-        memset(validity, 0, (n + 7) / 8);
-        // walk both columns chunk by chunk (no per-row binary search)
-        std::vector<uint8_t> ok(n, all_null ? 0 : 1);
-        for (int s = 0; s < 2 && !all_null; ++s) {
-            if (!col[s].any_null) continue;
-            if (lit[s]) continue; // a null literal is the all_null case above
-            for (const Chunk &k : col[s].chunks)
-                if (k.nulls)
-                    for (int64_t i = 0; i < k.a->length; ++i)
-                        if (!bit_at(k.nulls, k.a->offset + i)) ok[k.row0 + (uint64_t)i] = 0;
-        }
-        for (uint64_t i = 0; i < n; ++i) {
-            if (ok[i]) validity[i >> 3] |= (uint8_t)(1u << (i & 7));
-            else { ++null_count; out[i] = 0.0; }
-        }
+        validity = static_cast<uint8_t *>(alloc64((n + 63) / 64 * 8));
+        null_count = build_validity(col, lit, n, all_null, T, reinterpret_cast<uint64_t *>(validity), out);
     }
 
     // one "g" chunk
@@ -996,11 +1089,17 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     ret->len = 1;
     ret->release = release_series;
     ret->private_data = sp;
-    if (tm.on)
-        fprintf(stderr, "[polars_strsim] rows=%llu total=%.2f ms: pack=%.2f launch=%.2f wait=%.2f d2h=%.2f copy=%.2f\n",
+    if (tm.on) {
+        double launch = 0, wait = 0, d2h = 0;
+        for (const PipeTimes &p : ptimes) { launch += p.t_launch; wait += p.t_wait; d2h += p.t_d2h; }
+        fprintf(stderr, "[polars_strsim] rows=%llu total=%.2f ms: pack=%.2f launch=%.2f wait=%.2f d2h=%.2f copy=%.2f (threads %u, pipelines %zu)\n",
                 (unsigned long long)n,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), tm.t_pack,
-                tm.t_launch, tm.t_wait, tm.t_d2h, tm.t_copy);
+                launch, wait, d2h, tm.t_copy, T, ptimes.size());
+        for (size_t d = 0; d < ptimes.size(); ++d)
+            fprintf(stderr, "[polars_strsim]   pipeline %zu (device %d): %u slices, launch=%.2f wait=%.2f d2h=%.2f ms\n", d, devs[d],
+                    ptimes[d].slices, ptimes[d].t_launch, ptimes[d].t_wait, ptimes[d].t_d2h);
+    }
 }
 
 void plugin_entry(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, const CallerContext *cc)
@@ -1045,9 +1144,12 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_error.
         field_entry(input_fields, n_fields, return_value);                                                      \
     }
 
-// Test hook (no GPU needed): run the host-side packing of rows [r0, r1) of one Series with `threads` helper threads into
-// caller-provided buffers -- the exact describe / range_bytes / pack_range code the plugin entry points use.  Owns and
-// releases the input like a plugin call.  Returns 0, or -1 with the message in _polars_plugin_get_last_error_message().
+#ifdef STRSIM_TEST_HOOKS
+// Test hooks (no GPU needed), compiled only into tests/cpu_harness/libplugin_testhooks.so (make testhooks) -- the product library
+// does not export them.
+// (1) the host-side packing of rows [r0, r1) of one Series with `threads` helper threads into caller-provided buffers -- the exact
+// describe / range_bytes / pack_range code the plugin entry points use.  Owns and releases the input like a plugin call.
+// Returns 0, or -1 with the message in _polars_plugin_get_last_error_message().
 POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0, uint64_t r1, uint32_t *off_out,
                                                uint8_t *val_out, uint64_t val_cap, uint64_t *rows_out, uint64_t *bytes_out,
                                                uint8_t *valid_out, unsigned threads)
@@ -1080,6 +1182,32 @@ POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0
     }
     return -1;
 }
+
+// (2) the output validity of a call over two Series (a one-row side is the literal), as the plugin builds it: words[(n + 63) / 64]
+// and the null count; vals (optional, n doubles): the slots under nulls are zeroed.  Returns 0 / -1 like (1).
+POLARS_PLUGIN_API int _strsim_test_validity(SeriesExport *two_series, uint64_t *words, int64_t *null_count, double *vals,
+                                            uint64_t *rows_out, unsigned threads)
+{
+    InputGuard guard{two_series, 2};
+    try {
+        Column col[2];
+        describe(two_series[0], col[0]);
+        describe(two_series[1], col[1]);
+        if (col[0].rows != col[1].rows && col[0].rows != 1 && col[1].rows != 1) fail("shape");
+        const bool lit[2] = {col[0].rows == 1 && col[1].rows != 1, col[1].rows == 1};
+        const uint64_t n = lit[0] ? col[1].rows : col[0].rows;
+        if (rows_out) *rows_out = n;
+        const bool all_null = (lit[0] && !row_valid(col[0], 0)) || (lit[1] && !row_valid(col[1], 0));
+        *null_count = n ? build_validity(col, lit, n, all_null, threads ? threads : 1, words, vals) : 0;
+        return 0;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
+}
+#endif // STRSIM_TEST_HOOKS
 
 POLARS_PLUGIN_DEFINE(levenshtein, STRSIM_LEVENSHTEIN)
 POLARS_PLUGIN_DEFINE(jaro, STRSIM_JARO)

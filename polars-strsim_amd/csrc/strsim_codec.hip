@@ -416,9 +416,12 @@ int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint6
 {
     if (!ctx || !offsets || (!lengths && rows)) { set_error("strsim_offsets_from_lengths: NULL argument"); return STRSIM_ERR_ARG; }
     const uint64_t nblk = (rows + LEN_ROWS - 1) / LEN_ROWS;
-    if (nblk > strsim::SCAN_WS_WORDS) {
-        set_error("strsim_offsets_from_lengths: %llu rows in one call; at most %llu", (unsigned long long)rows,
-                  (unsigned long long)(strsim::SCAN_WS_WORDS * (uint64_t)LEN_ROWS));
+    // the running sum is 32 bits wide, like the offsets themselves: a call may hold only as many rows as cannot wrap it
+    // whatever the lengths are (255 each)
+    const uint64_t max_rows = std::min<uint64_t>(strsim::SCAN_WS_WORDS * (uint64_t)LEN_ROWS, (uint64_t)STRSIM_OFFSETS_FROM_LENGTHS_MAX_ROWS);
+    if (rows > max_rows) {
+        set_error("strsim_offsets_from_lengths: %llu rows in one call; at most %llu (32-bit offsets of strings of up to 255 bytes)",
+                  (unsigned long long)rows, (unsigned long long)max_rows);
         return STRSIM_ERR_ARG;
     }
     if (reinterpret_cast<uintptr_t>(lengths) & 15u) { set_error("strsim_offsets_from_lengths: lengths must be 16-byte aligned"); return STRSIM_ERR_ARG; }

@@ -165,32 +165,3 @@ def plugin_version():
     L._polars_plugin_get_version.restype = C.c_uint32
     v = L._polars_plugin_get_version()
     return v >> 16, v & 0xFFFF
-
-
-def pack_series(x, layout="vu", r0=0, r1=None, threads=1):
-    """Run the plugin's host-side packer on one column (test hook, no GPU): -> (offsets u32, values u8, validity bool)."""
-    import numpy as np
-    L = _load()
-    fn = L._strsim_test_pack_series
-    fn.restype = C.c_int
-    fn.argtypes = [C.POINTER(SeriesExport), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
-                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_uint]
-    L._polars_plugin_get_last_error_message.restype = C.c_char_p
-    chunks, dtype = _chunks(x, layout)
-    n = sum(len(c) for c in chunks)
-    if r1 is None:
-        r1 = n
-    nbytes = sum(c.nbytes for c in chunks) + 64 * (n + 1)
-    ex = _Exported("col", chunks, dtype)
-    se = SeriesExport()
-    ex.fill(se)
-    off = np.zeros(max(r1 - r0, 0) + 1, dtype=np.uint32)
-    val = np.zeros(nbytes + 64, dtype=np.uint8)
-    valid = np.zeros(max(r1 - r0, 0) + 1, dtype=np.uint8)
-    rows, used = C.c_uint64(), C.c_uint64()
-    rc = fn(C.byref(se), r0, r1, off.ctypes.data, val.ctypes.data, val.size, C.byref(rows), C.byref(used), valid.ctypes.data,
-            threads)
-    if rc != 0:
-        raise PluginError(L._polars_plugin_get_last_error_message().decode())
-    assert ex.released == 1 and ex.arrays_released()
-    return off, val[: used.value], valid[: max(r1 - r0, 0)].astype(bool), rows.value

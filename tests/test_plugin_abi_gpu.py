@@ -177,11 +177,16 @@ def test_concurrent_calls_from_several_threads(H):
 @pytest.mark.parametrize("devices,min_rows", [("0,0", "1000"), ("0,0,0", "50000")])
 def test_rows_shard_over_several_device_pipelines(H, monkeypatch, devices, min_rows):
     """One plugin call, several device pipelines (the reference fans rows out over its threads inside the call,
-    strsim.rs:72-100): rows are cut by split_offsets(n, devices) (strsim.rs:21-39), every shard runs on its own host thread
-    with its own context and pinned slots.  A one-GPU box runs the shards as several contexts on device 0; nulls, a literal
-    and strings that need the slow kernels included; then the same thread goes back to one device."""
+    strsim.rs:72-100): the call's slices are dealt out to the pipelines in turn, each with its own context, streams and pinned
+    slots, two slices in flight per pipeline.  A one-GPU box runs them as several contexts on device 0; the slice sizes are
+    shrunk so that this small frame is a dozen slices; nulls, a literal and strings that need the slow kernels included (their
+    kernels are launched when a slice is retired: the column is fetched again); then the same thread goes back to one device."""
     monkeypatch.setenv("POLARS_STRSIM_DEVICES", devices)
     monkeypatch.setenv("POLARS_STRSIM_MIN_ROWS_PER_DEVICE", min_rows)
+    monkeypatch.setenv("POLARS_STRSIM_SINGLE_SLICE_ROWS", "10000")
+    monkeypatch.setenv("POLARS_STRSIM_RAMP_ROWS", "40000")
+    monkeypatch.setenv("POLARS_STRSIM_SLICE_ROWS", "40000")
+    monkeypatch.setenv("POLARS_STRSIM_DIRECT_ROWS", "0")
     A, B = gen.pairs(77, 200_003, gen.ASCII_LOWER, 0, 40)
     A2, B2 = gen.pairs(78, 3000, gen.MIXED, 0, 150)
     A, B = A + A2, B + B2
@@ -194,6 +199,8 @@ def test_rows_shard_over_several_device_pipelines(H, monkeypatch, devices, min_r
     check(H.call_plugin("jaro", "philips", B), expect("jaro", ["philips"], B))
     monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
     check(H.call_plugin("sorensen_dice", A[:70000], B[:70000]), expect("sorensen_dice", A[:70000], B[:70000]))
+    monkeypatch.delenv("POLARS_STRSIM_DEVICES")  # the default: one device, the calling thread's current one
+    check(H.call_plugin("jaccard", A[:70000], B[:70000]), expect("jaccard", A[:70000], B[:70000]))
 
 
 def test_large_call_with_and_without_pinned_result_and_length_bytes(H, monkeypatch):
@@ -218,7 +225,7 @@ def test_large_call_with_and_without_pinned_result_and_length_bytes(H, monkeypat
 
 def test_large_call_over_two_pipelines_lands_in_one_pinned_column(H, monkeypatch):
     """4.6 M rows: enough for two device pipelines at the default rows-per-device threshold, and a result column that comes
-    from the pinned pool -- both pipelines' copy engines write their halves of it directly.  Equal, bit for bit, to the
+    from the pinned pool -- both pipelines' copy engines write their slices of it directly.  Equal, bit for bit, to the
     one-pipeline call (whose parity with the oracle the other tests establish)."""
     import os
     import sys

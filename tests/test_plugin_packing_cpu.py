@@ -8,7 +8,7 @@ import pyarrow as pa
 import pytest
 
 import gen
-from strsim_amd import arrow_host as H
+import pack_harness as H
 
 
 def expected(strings, r0, r1):
@@ -70,3 +70,36 @@ def test_view_inline_boundary_and_empty():
 def test_dtype_error_from_the_packer():
     with pytest.raises(H.PluginError, match="invalid series dtype"):
         H.pack_series(pa.array([1, 2, 3]))
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_output_validity_is_the_and_of_the_inputs(threads):
+    """The word-wise validity builder against plain Python: chunk boundaries and Arrow offsets that are not multiples of 8 or
+    64, one side without nulls, a literal side, a null literal, n not a multiple of 64; null slots get 0.0 in the values."""
+    rng = random.Random(4)
+    for n in (1, 63, 64, 65, 1000, 300_000 + 37):
+        A = [None if rng.random() < 0.15 else "x" for _ in range(n)]
+        B = [None if rng.random() < 0.05 else "y" for _ in range(n)]
+        pa_a, pa_b = pa.array(A, type=pa.string()), pa.array(B, type=pa.string())
+        cuts = sorted({0, n, *(rng.randrange(n + 1) for _ in range(4))})
+        ca = pa.chunked_array([pa_a[i:j] for i, j in zip(cuts[:-1], cuts[1:])] or [pa_a])
+        cutsb = sorted({0, n, *(rng.randrange(n + 1) for _ in range(2))})
+        cb = pa.chunked_array([pa_b[i:j] for i, j in zip(cutsb[:-1], cutsb[1:])] or [pa_b])
+        exp = np.array([x is not None and y is not None for x, y in zip(A, B)])
+        vals = np.full(n, 7.0)
+        got, nulls = H.validity(ca, cb, threads=threads, vals=vals)
+        assert (got == exp).all() and nulls == int((~exp).sum()), n
+        assert (vals[~exp] == 0.0).all() and (vals[exp] == 7.0).all()
+        for layouts in (("u", "vu"), ("U", "u")):
+            got, nulls = H.validity(ca, cb, layouts=layouts, threads=threads)
+            assert (got == exp).all() and nulls == int((~exp).sum())
+        # one side without nulls; a literal on either side; a null literal
+        got, nulls = H.validity(ca, ["z"] * n, threads=threads)
+        assert (got == np.array([x is not None for x in A])).all()
+        if n > 1:
+            got, nulls = H.validity(ca, "lit", threads=threads)
+            assert (got == np.array([x is not None for x in A])).all() and nulls == sum(x is None for x in A)
+            got, nulls = H.validity("lit", cb, threads=threads)
+            assert (got == np.array([y is not None for y in B])).all()
+            got, nulls = H.validity(ca, None, threads=threads)
+            assert not got.any() and nulls == n
