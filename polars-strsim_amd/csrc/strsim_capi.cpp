@@ -82,6 +82,7 @@ struct strsim_ctx {
     // the long-string pass -- and the next calls enqueue the whole chain up front again.
     bool slot_deferred[RING] = {};
     bool expect_slow = false;
+    bool long_rows = false;        // ... and left more than 1/16 of its rows: frames of long strings (see k_lane_stage, TABLES)
     bool stream_ordered = false;   // strsim_ctx_set_stream_ordered: never defer
     uint64_t last_late_rows = 0;   // rows finished by a pass launched from synchronize / retire (deferred + long-string)
     hipEvent_t ev_late[2] = {};    // timing of a deferred slow pass
@@ -233,7 +234,10 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
         return STRSIM_ERR_INTERNAL;
     }
     const uint32_t left = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].lane_left);
-    if (left != LANE_LEFT_UNKNOWN) c->expect_slow = left != 0u; // what the next call on this context is enqueued for
+    if (left != LANE_LEFT_UNKNOWN) { // what the next call on this context is enqueued for
+        c->expect_slow = left != 0u;
+        c->long_rows = (uint64_t)left * 16u > c->slot_args[s].n;
+    }
     if (c->slot_timed[s]) {
         float a = 0, b = 0;
         // (the ticket says the kernels are done; the event right behind them may be a moment later)
@@ -486,6 +490,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
     la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
     la.no_literal_path = getenv("STRSIM_NO_LITERAL_PATH") != nullptr; // (tuning / A-B knob)
+    la.long_rows = c->long_rows;
     la.wide_grid = c->num_cu * 3; // resident (LDS)
     {
         int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)

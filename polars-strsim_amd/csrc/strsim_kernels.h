@@ -57,6 +57,7 @@ struct LaunchArgs {
     hipStream_t stream;
     int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
     bool no_literal_path;         // A/B runs: a literal call takes k_lane_stage like any other
+    bool long_rows;               // the context's last call left many rows behind k_lane_stage: take its instantiation without tables
     int stage_grid;               // > 0: k_lane_stage (bytes staged through LDS) with this many persistent workgroups
     int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)

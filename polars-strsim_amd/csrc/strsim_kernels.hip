@@ -1854,11 +1854,19 @@ static void launch_lane_t(const LaunchArgs &a)
     } else if (a.stage_grid > 0) {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
-        // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; a measure that runs fewer gets its share)
-        const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
-        const uint64_t gs = stage_launch_size(nsb, res, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
-        hipLaunchKernelGGL((k_lane_stage<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
+        // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; an instantiation that runs fewer gets its share)
+        auto go = [&](auto tables) {
+            constexpr bool T = decltype(tables)::value;
+            const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M, T>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
+            const uint64_t gs = stage_launch_size(nsb, res, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
+            hipLaunchKernelGGL((k_lane_stage<M, T>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+                               a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
+        };
+        if constexpr (stage_uses_lut<M>()) {
+            if (a.long_rows) go(std::false_type{}); else go(std::true_type{});
+        } else {
+            go(std::false_type{});
+        }
     } else {
         hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
@@ -1950,7 +1958,7 @@ hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5])
     if (a.stage_grid > 0) {
         // one staged pass, five outputs (strsim_lane_stage.h, MEASURE = ALL_MEASURES)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
-        const uint64_t cap = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<ALL_MEASURES>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU; // resident workgroups
+        const uint64_t cap = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>()>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU; // resident workgroups
         const uint64_t gs = stage_launch_size(nsb, cap, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
         hipLaunchKernelGGL(k_lane_stage_all, dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA,
                            a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host,

@@ -31,7 +31,7 @@
 #define STRSIM_STAGE_ROWS 512
 #endif
 #ifndef STRSIM_STAGE_CAP
-#define STRSIM_STAGE_CAP 9216 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB; a block that does not fit is cut)
+#define STRSIM_STAGE_CAP 10240 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB; a block that does not fit is cut)
 #endif
 #ifndef STRSIM_STAGE_CAP_LUT
 #define STRSIM_STAGE_CAP_LUT 8960 // the same for the instantiations with match-mask tables (40 KB of LDS: four workgroups per CU)
@@ -102,8 +102,8 @@ template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_L
 template <int MEASURE> constexpr bool stage_uses_mlut() { return !stage_uses_lut<MEASURE>() && ((STRSIM_STAGE_MLUT >> MEASURE) & 1) != 0; }
 
 // staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
-template <int MEASURE> struct StageGeom {
-    static constexpr int CAP = stage_uses_lut<MEASURE>() ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP;
+template <bool TABLES> struct StageGeom {
+    static constexpr int CAP = TABLES ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP;
     static constexpr int COL = CAP + 96;              // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
     static constexpr int DMA_ITERS = (CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
     static_assert(CAP % 16 == 0 && 2 * COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
@@ -306,11 +306,10 @@ __device__ __forceinline__ double stage_epilogue(uint32_t pk, double qa, double 
 }
 
 // `last`: the round's last lane that holds a row of this kernel (uniform)
-template <int MEASURE>
+template <int MEASURE, bool LUT>
 __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta,
                                               uint32_t last, uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
-    constexpr bool LUT = stage_uses_lut<MEASURE>();
     constexpr int LUTMODE = LUT ? 1 : (stage_uses_mlut<MEASURE>() ? 2 : 0);
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
@@ -362,7 +361,7 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
     }
 }
 
-template <int MEASURE>
+template <int MEASURE, bool LUT>
 __device__ __forceinline__ void
 lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs,
@@ -373,12 +372,12 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
-    constexpr int STAGE_CAP = StageGeom<MEASURE>::CAP, STAGE_COL = StageGeom<MEASURE>::COL;
-    constexpr int STAGE_DMA_ITERS = StageGeom<MEASURE>::DMA_ITERS;
+    constexpr int STAGE_CAP = StageGeom<LUT>::CAP, STAGE_COL = StageGeom<LUT>::COL;
+    constexpr int STAGE_DMA_ITERS = StageGeom<LUT>::DMA_ITERS;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
-    constexpr bool LUT = stage_uses_lut<MEASURE>(), MLUT = stage_uses_mlut<MEASURE>();
+    constexpr bool MLUT = !LUT && stage_uses_mlut<MEASURE>();
     // The 1 KB behind each wave's tables holds 128 of the block's row descriptors (without tables: an array of their own).
     static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
     // (the small table: 1 KB per wave at a 1 KB boundary)
@@ -764,7 +763,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             __builtin_amdgcn_s_setprio(0);
 #endif
             const uint32_t in_round = nmine - r * 64u; // (>= 1)
-            stage_compute<MEASURE>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
+            stage_compute<MEASURE, LUT>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
             STAGE_STAMP(8);
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
@@ -820,28 +819,31 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
 #define STRSIM_STAGE_ALL_WAVES_PER_EU 3
 #endif
-template <int MEASURE> constexpr int stage_waves_per_eu()
+template <int MEASURE, bool TABLES> constexpr int stage_waves_per_eu()
 {
-    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : (stage_uses_lut<MEASURE>() ? 4 : 5);
+    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : (TABLES ? 4 : 5);
     return STRSIM_STAGE_WAVES_PER_EU < lim ? STRSIM_STAGE_WAVES_PER_EU : lim;
 }
 
-template <int MEASURE>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE>()))) void
+// TABLES: match masks from the LDS tables (a measure whose bit is set in STRSIM_STAGE_LUT has both instantiations; the launcher
+// takes the one without tables for frames with many rows this kernel leaves to the others -- long strings: what the kernel does
+// there is mostly staging, which the larger staging area and the fifth workgroup per CU serve better; cfg3: 2.86 vs 2.57 ms)
+template <int MEASURE, bool TABLES>
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE, TABLES>()))) void
 k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
              unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
              uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
+    lane_stage_body<MEASURE, TABLES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }
 
 // The five-output instantiation keeps the matching state of three cores alive at once and stages 64 bits per row.
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<ALL_MEASURES>()))) void
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>()>()))) void
 k_lane_stage_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
                  unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
                  uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
+    lane_stage_body<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>()>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }
