@@ -270,6 +270,8 @@ def main():
         step(i)
     drain()
     ctx.timing(True)
+    if shipper is not None:
+        shipper.timing_begin()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -286,6 +288,20 @@ def main():
     tm = ctx.timing_read()
     ctx.timing(False)
     wave_rows = ctx.last_wave_rows
+    ship_ms, decode_ms = shipper.timing_end() if shipper is not None else (None, None)
+    # what each rank spent per step, so that a scaling record can be read: kernels, its shipment, its wall clock
+    per_rank = None
+    if world > 1:
+        cdev_ = dev if a.backend == "nccl" else "cpu"
+        mine_ = torch.tensor([tm["lane_ms"] / max(tm["lane_launches"], 1) * nparts,
+                              tm["wave_ms"] / max(tm["wave_launches"], 1) * nparts, ship_ms if ship_ms is not None else -1.0,
+                              dt / a.steps * 1e3, float(rows)], dtype=torch.float64, device=cdev_)
+        all_ = [torch.zeros_like(mine_) for _ in range(world)]
+        dist.all_gather(all_, mine_)
+        per_rank = [{"rank": r, "rows": int(v[4].item()), "lane_kernel_ms_per_pass": round(float(v[0].item()), 4),
+                     "slow_row_kernels_ms_per_pass": round(float(v[1].item()), 4),
+                     "shipment_ms_per_column": None if float(v[2].item()) < 0 else round(float(v[2].item()), 4),
+                     "wall_ms_per_step": round(float(v[3].item()), 4)} for r, v in enumerate(all_)]
 
     gather_ok = None
     if world > 1:
@@ -351,7 +367,8 @@ def main():
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
                        "gather_verified": gather_ok, "gather_note": gather_note,
-                       "rows_on_wave_kernel": wave_rows, "enqueued_kernels_and_copies_per_step": ops_per_step},
+                       "rows_on_wave_kernel": wave_rows, "enqueued_kernels_and_copies_per_step": ops_per_step,
+                       "per_rank": per_rank, "root_decode_ms_per_column": None if decode_ms is None else round(decode_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_read_bytes": read_bytes, "algorithmic_write_bytes": write_bytes,

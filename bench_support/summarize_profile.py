@@ -27,11 +27,15 @@ def traffic_json(out, key, kernel="k_lane_stage"):
         f = find(os.path.join(out, grp), "*counter_collection.csv")
         if not f:
             return
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-             if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr]
-        if not v:
-            return
-        vals[ctr] = sum(v) / len(v)
+        # "k_a+k_b": the pass consists of both kernels -- per-launch means, added up
+        tot = 0.0
+        for kname in kernel.split("+"):
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                 if kname in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if not v:
+                return
+            tot += sum(v) / len(v)
+        vals[ctr] = tot
     import hashlib
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     lib = os.environ.get("STRSIM_AMD_LIB") or os.path.join(root, "polars-strsim_amd", "polars_strsim", "libpolars_strsim_amd.so")

@@ -89,6 +89,8 @@ class ShardGatherer:
         self.ctx_comm = S.Context(ctx.device, stream=self.comm.cuda_stream)
         self.ctx_decode = S.Context(ctx.device, stream=self.decode.cuda_stream)
         self.nsub = 0
+        self.timing = False      # timing_begin(): event pairs around every shipment (encode + gather) and every root decode
+        self._t_ship, self._t_dec = [], []
         self.codecs = {}
         if codec_chars:
             for m in measures:
@@ -146,6 +148,9 @@ class ShardGatherer:
             raise ValueError(f"rank {self.rank}: shard has {out.numel()} rows, expected {self.rows}")
         self.comm.wait_stream(self.compute)
         with torch.cuda.stream(self.comm):
+            if self.timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(self.comm)
             if codec is not None:
                 buf = self.codes.get(slot)
                 if buf is None:
@@ -166,6 +171,9 @@ class ShardGatherer:
                 if self.rank == 0:
                     self.decode.wait_stream(self.comm)
                     with torch.cuda.stream(self.decode):
+                        if self.timing:
+                            d0 = torch.cuda.Event(enable_timing=True)
+                            d0.record(self.decode)
                         rc = self.recv_codes[b].to(self.dev) if self.host else self.recv_codes[b]
                         for r, (off, ln) in enumerate(self.parts):  # every rank coded its own shard: decode them one by one
                             seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes]
@@ -176,8 +184,10 @@ class ShardGatherer:
                                 codec.decode(seg[:2 * ln].view(torch.int16), dst, ctx=self.ctx_decode)
                             codec.patch_indirect(self.recv, off, self._exc_views(seg, self.code_bytes), self.overflow,
                                                  ctx=self.ctx_decode)
-                        self.decoded[b] = torch.cuda.Event()
+                        self.decoded[b] = torch.cuda.Event(enable_timing=self.timing)
                         self.decoded[b].record(self.decode)
+                        if self.timing:
+                            self._t_dec.append((d0, self.decoded[b]))
             else:
                 ragged = any(p[1] != self.cap_rows for p in self.parts)
                 src = out.cpu() if self.host else out
@@ -191,9 +201,11 @@ class ShardGatherer:
                 if self.rank == 0 and ragged and not self.host:
                     for r, (off, ln) in enumerate(self.parts):
                         self.recv[off:off + ln].copy_(self.recv_pad[r * self.cap_rows:r * self.cap_rows + ln], non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(self.comm)
             self.done[slot] = ev
+            if self.timing:
+                self._t_ship.append((t0, ev))
 
     def result(self):
         """Rank 0, after drain(): the gathered f64 column of the last shipment (total rows); None elsewhere."""
@@ -211,6 +223,20 @@ class ShardGatherer:
         if self.rank == 0 and int(self.overflow.item()) != 0:
             raise RuntimeError("ShardGatherer: a rank had more rows outside the codec's table than its exception block "
                                f"holds ({self.exc_ship}); ship this column as f64 (codec_chars=None) or raise exc_ship")
+
+    def timing_begin(self):
+        """From now on every shipment and every root-side decode is bracketed by timed events on its own stream."""
+        self.timing = True
+        self._t_ship, self._t_dec = [], []
+
+    def timing_end(self):
+        """After drain(): (mean ms of a shipment on the comm stream: encode + gather as this rank saw it, mean ms of a
+        root-side decode + exception patch, None on other ranks); resets."""
+        ship = [a.elapsed_time(b) for a, b in self._t_ship]
+        dec = [a.elapsed_time(b) for a, b in self._t_dec]
+        self.timing = False
+        self._t_ship, self._t_dec = [], []
+        return (sum(ship) / len(ship) if ship else None), (sum(dec) / len(dec) if dec else None)
 
     def exceptions(self):
         """Rows outside the codec's table in the LAST shard this rank coded (they travelled in the exception block)."""
