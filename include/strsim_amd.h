@@ -176,6 +176,16 @@ STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms,
 #define STRSIM_OFFSETS_FROM_LENGTHS_MAX_ROWS 16843009u
 STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets);
 
+/* Close the gaps between up to STRSIM_COMPACT_MAX_SEGMENTS byte segments on the device, one launch on the context's stream:
+ * dst[dst_off[k] .. + bytes[k]) = src[src_off[k] .. + bytes[k]) for k < nseg; src and dst are distinct device buffers, the three
+ * arrays are host memory (read before the call returns).  For a host that packs a column's values with several threads in ONE
+ * pass -- each thread into its own segment of a staging buffer, no common prefix, one length byte per row (see
+ * strsim_offsets_from_lengths) -- and ships the buffer as it lies: the plugin layer does (reference counterpart: none; the
+ * reference iterates the views in place, strsim.rs:46-47). */
+#define STRSIM_COMPACT_MAX_SEGMENTS 32
+STRSIM_API int strsim_compact_segments(strsim_ctx_t *ctx, const uint8_t *src, uint8_t *dst, const uint64_t *src_off,
+                                       const uint64_t *dst_off, const uint64_t *bytes, int nseg);
+
 /* For a caller that keeps several calls in flight on the context's stream and learns of their completion by its own means
  * (an event recorded on strsim_ctx_stream() behind each call): retire the OLDEST pending call only -- what
  * strsim_ctx_synchronize() does for all of them, without waiting for the younger ones.  The caller guarantees that the
@@ -246,6 +256,15 @@ STRSIM_API int strsim_codec_patch(strsim_ctx_t *ctx, double *out, uint64_t row_b
 STRSIM_API int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint64_t row_base, const uint32_t *exc_count,
                                            const uint32_t *exc_rows, const double *exc_vals, uint32_t exc_cap,
                                            uint32_t *overflow);
+
+/* The root's side of a gather in ONE launch: `buf` holds nseg segments seg_stride_bytes apart, segment r = rank r's codes (packed:
+ * strsim_codec_encode_packed's words; else 16-bit codes) followed, code_bytes into the segment, by its exception block -- count
+ * (u32, 16-byte field), exc_cap rows (u32), exc_cap values (f64).  Rows r * chunk_rows .. (last segment: last_rows of them) of `out`
+ * are decoded and the exceptions written in; a count above exc_cap increments *overflow (device).  Replaces one
+ * strsim_codec_decode(_packed) + one strsim_codec_patch_indirect launch per peer (strsim_amd/distributed.py). */
+STRSIM_API int strsim_codec_decode_gathered(strsim_ctx_t *ctx, const strsim_codec_t *codec, const void *buf, uint64_t seg_stride_bytes,
+                                            uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed, uint64_t code_bytes,
+                                            uint32_t exc_cap, double *out, uint32_t *overflow);
 
 #define STRSIM_LANE_PATH_MAX_BYTES 32u   /* lane-per-pair kernels: both strings <= 32 bytes, ASCII */
 #define STRSIM_WAVE_PATH_MAX_BYTES 1024u /* wave-per-pair kernels: both strings <= 1024 bytes, any UTF-8 */

@@ -198,6 +198,44 @@ void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64
     }
 }
 
+// The one-pass form for a column of views whose strings fit one length byte: rows [r0, r1) into the thread's OWN segment
+// val[base .. limit), one length byte per row into len8 -- no size pass, hence no common prefix between the threads: the gaps
+// between the segments are closed on the device (strsim_compact_segments).  Returns the bytes used, or ~0 when the
+// segment overflows or a string exceeds 255 bytes (the caller then packs the slice the two-pass way).
+uint64_t pack_range_onepass(const Column &c, uint64_t r0, uint64_t r1, uint64_t base, uint64_t limit, uint8_t *val, uint8_t *len8)
+{
+    uint64_t pos = base;
+    for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        const ArrowArray *a = k.a;
+        const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
+        const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)a->length) - k.row0);
+        const View *v = static_cast<const View *>(a->buffers[1]) + a->offset;
+        const int64_t *sizes = a->n_buffers >= 4 ? static_cast<const int64_t *>(a->buffers[a->n_buffers - 1]) : nullptr;
+        const int64_t nvar = sizes ? a->n_buffers - 3 : a->n_buffers - 2; // variadic data buffers
+        for (int64_t i = i0; i < i1; ++i) {
+            if (k.nulls && !bit_at(k.nulls, a->offset + i)) { *len8++ = 0; continue; }
+            const uint32_t len = v[i].len;
+            if (len > 255u || pos + len > limit) return ~0ull;
+            const bool inl = len <= 12;
+            uint32_t bi, bo;
+            memcpy(&bi, v[i].rest + 4, 4);
+            memcpy(&bo, v[i].rest + 8, 4);
+            if (!inl && (int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+            const uint32_t bsel = inl ? 0u : bi;
+            const uint8_t *data = nvar > 0 ? static_cast<const uint8_t *>(a->buffers[2 + bsel]) : nullptr;
+            const uint8_t *src = inl ? v[i].rest : data + bo;
+            // (the fixed 32-byte copy of pack_range: see there)
+            const bool room = inl ? i + 2 < a->length : (sizes != nullptr && (int64_t)bo + 32 <= sizes[bsel]);
+            if (len <= 32 && room && pos + 32 <= limit) memcpy(val + pos, src, 32);
+            else memcpy(val + pos, src, len);
+            pos += len;
+            *len8++ = (uint8_t)len;
+        }
+    }
+    return pos - base;
+}
+
 // ---- input ownership -------------------------------------------------------------------------------
 struct InputGuard { // the callee owns the inputs: release every array, then every SeriesExport, exactly once
     SeriesExport *in;
@@ -501,14 +539,20 @@ struct Slot {
     Buf h_off[2], h_val[2], h_out, d_off[2], d_val[2], d_out;
     Buf h_len[2], d_len[2]; // one length byte per row, shipped instead of the offsets when lens8[s] (see pack_slice2)
     bool lens8[2] = {false, false};
+    // one-pass packing (pack_slice_onepass): nseg[s] > 1: the values of column s sit in nseg[s] segments of h_val[s] (seg_src,
+    // seg_bytes), are shipped in one copy into d_land[s] and moved to their final places in d_val[s] (seg_dst) on the device
+    int nseg[2] = {0, 0};
+    uint64_t seg_src[2][32], seg_dst[2][32], seg_bytes[2][32];
+    uint64_t span[2] = {0, 0}; // bytes of h_val[s] to ship (the last segment's end)
+    Buf d_land[2];
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
     bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
     hipEvent_t ev_kernels = nullptr, ev_results = nullptr; // behind the slice's kernels (compute stream) / its D2H (copy stream)
-    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; } d_out.device = true; }
+    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; d_land[i].device = true; } d_out.device = true; }
     void release()
     {
-        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); }
+        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); d_land[i].release(); }
         h_out.release(); d_out.release();
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev_results) (void)hipEventDestroy(ev_results);
@@ -688,6 +732,7 @@ bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, boo
     auto lo = [&](unsigned t) { return r0 + rows * t / T; };
     fork_join(T, [&](unsigned t) { for (int s = 0; s < 2; ++s) part[s][t + 1] = range_bytes(col[s], lo(t), lo(t + 1), &mx[s][t]); });
     for (int s = 0; s < 2; ++s) {
+        sl.nseg[s] = 0;
         for (unsigned t = 0; t < T; ++t) part[s][t + 1] += part[s][t];
         bytes[s] = part[s][T];
         // a column of views whose strings all fit a byte ships LENGTHS (1 B per row instead of a 4-byte offset over PCIe)
@@ -712,6 +757,53 @@ bool pack_slice2(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, boo
             pack_range(col[s], lo(t), lo(t + 1), o[s] ? o[s] + (lo(t) - r0) : nullptr, part[s][t], part[s][t + 1],
                        static_cast<uint8_t *>(val[s].p), l8[s] ? l8[s] + (lo(t) - r0) : nullptr);
     });
+    return true;
+}
+
+// ONE pass over both view columns of a slice (no size pass): thread t packs rows lo(t) .. lo(t+1) of each column into its own
+// segment of the staging area, sized from `bpr256[s]` -- the bytes per row (x 256) the call's previous slice had, plus slack --
+// and writes one length byte per row.  True on success (sl.bytes, sl.nseg / seg_*, sl.span and bpr256 updated); false when a
+// segment overflowed or a string exceeds 255 bytes: the caller packs the slice the two-pass way (which also re-learns bpr256).
+bool pack_slice_onepass(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, uint64_t (&bpr256)[2], unsigned T)
+{
+    const uint64_t rows = r1 - r0;
+    T = (unsigned)std::min<uint64_t>(std::min<unsigned>(T, 32u), std::max<uint64_t>(rows / 16384, 1));
+    auto lo = [&](unsigned t) { return r0 + rows * t / T; };
+    uint64_t base[2][33];
+    for (int s = 0; s < 2; ++s) {
+        base[s][0] = 0;
+        for (unsigned t = 0; t < T; ++t) {
+            const uint64_t n = lo(t + 1) - lo(t);
+            const uint64_t cap = ((n * bpr256[s]) >> 8) + (n >> 4) + 4096; // the estimate + 1/16 + 4 KB of slack
+            base[s][t + 1] = base[s][t] + ((cap + 63) & ~(uint64_t)63);
+        }
+        if (base[s][T] > SLICE_BYTES) return false;
+        sl.h_val[s].reserve(base[s][T] + 64);
+        sl.h_len[s].reserve(rows + 16);
+    }
+    uint64_t used[2][32];
+    fork_join(T, [&](unsigned t) {
+        for (int s = 0; s < 2; ++s)
+            used[s][t] = pack_range_onepass(col[s], lo(t), lo(t + 1), base[s][t], base[s][t + 1], static_cast<uint8_t *>(sl.h_val[s].p),
+                                            static_cast<uint8_t *>(sl.h_len[s].p) + (lo(t) - r0));
+    });
+    for (int s = 0; s < 2; ++s)
+        for (unsigned t = 0; t < T; ++t)
+            if (used[s][t] == ~0ull) return false;
+    for (int s = 0; s < 2; ++s) {
+        uint64_t total = 0;
+        for (unsigned t = 0; t < T; ++t) {
+            sl.seg_src[s][t] = base[s][t];
+            sl.seg_dst[s][t] = total;
+            sl.seg_bytes[s][t] = used[s][t];
+            total += used[s][t];
+        }
+        sl.nseg[s] = (int)T;
+        sl.span[s] = base[s][T - 1] + used[s][T - 1];
+        sl.bytes[s] = total;
+        sl.lens8[s] = true;
+        bpr256[s] = rows ? (total * 256 + rows - 1) / rows : 0;
+    }
     return true;
 }
 
@@ -783,13 +875,22 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
     // (slices computed in place read their offsets from the pinned staging; POLARS_STRSIM_LENGTH_BYTES=0: always ship offsets)
     const char *lens8_env = getenv("POLARS_STRSIM_LENGTH_BYTES");
     const bool lens8_ok = !(lens8_env && atoi(lens8_env) == 0) && !direct_call;
+    // bytes per row (x 256) of the call's last slice, per column: 0 = not known yet (the first slice is packed the two-pass way)
+    uint64_t bpr256[2] = {0, 0};
+    const char *onepass_env = getenv("POLARS_STRSIM_ONE_PASS");
+    const bool onepass_ok = lens8_ok && !lit[0] && !lit[1] && col[0].layout == L_VIEW && col[1].layout == L_VIEW &&
+                            !(onepass_env && atoi(onepass_env) == 0);
     auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
         uint64_t rows = std::min<uint64_t>(want, n - r0);
         for (;;) {
             bool fits = true;
             sl.lens8[0] = sl.lens8[1] = false;
-            if (!lit[0] && !lit[1]) {
+            sl.nseg[0] = sl.nseg[1] = 0;
+            if (onepass_ok && bpr256[0] && bpr256[1] && pack_slice_onepass(col, r0, r0 + rows, sl, bpr256, T)) {
+                // (one pass: lengths + values in per-thread segments)
+            } else if (!lit[0] && !lit[1]) {
                 fits = pack_slice2(col, r0, r0 + rows, sl, lens8_ok, T);
+                for (int s = 0; s < 2 && fits; ++s) bpr256[s] = sl.lens8[s] && rows ? (sl.bytes[s] * 256 + rows - 1) / rows + 1 : 0;
             } else {
                 for (int s = 0; s < 2 && fits; ++s) {
                     if (lit[s]) continue;
@@ -833,7 +934,15 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
             } else {
                 HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             }
-            if (sl.bytes[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
+            if (sl.nseg[s] > 1) { // one-pass slice: one copy of the segments as they lie, then the gaps are closed on the device
+                sl.d_land[s].reserve(sl.span[s] + 64);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_land[s].p, sl.h_val[s].p, sl.span[s], hipMemcpyHostToDevice, stream));
+                if (strsim_compact_segments(ctx, static_cast<const uint8_t *>(sl.d_land[s].p), static_cast<uint8_t *>(sl.d_val[s].p),
+                                                     sl.seg_src[s], sl.seg_dst[s], sl.seg_bytes[s], sl.nseg[s]) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+            } else if (sl.bytes[s]) {
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
+            }
             doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
             dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
         }
@@ -1175,6 +1284,50 @@ POLARS_PLUGIN_API int _strsim_test_pack_series(SeriesExport *series, uint64_t r0
         if (valid_out)
             for (uint64_t r = r0; r < r1; ++r) valid_out[r - r0] = row_valid(c, r) ? 1 : 0;
         return 0;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
+}
+
+// (1b) the ONE-PASS packer on one view Series used for both columns of a slice: rows [r0, r1) on `threads` threads with a budget of
+// bpr256 / 256 bytes per row.  Returns 1 and fills val_out (the segments CLOSED UP the way the device does: seg_dst order),
+// len_out (one byte per row) and *bytes_out when the pass succeeds, 0 when it reports "overflow / long string" (the plugin then
+// packs two-pass), -1 on error.
+POLARS_PLUGIN_API int _strsim_test_pack_onepass(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t bpr256, unsigned threads,
+                                                uint8_t *val_out, uint64_t val_cap, uint8_t *len_out, uint64_t *bytes_out, int *nseg_out)
+{
+    InputGuard guard{series, 1};
+    try {
+        Column col[2];
+        describe(*series, col[0]);
+        describe(*series, col[1]);
+        if (col[0].layout != L_VIEW) fail("one-pass packing is for view columns");
+        if (r1 > col[0].rows) r1 = col[0].rows;
+        if (r0 > r1) r0 = r1;
+        Slot sl; // (plain memory stands in for the pinned staging: generous enough that reserve() never allocates -- no GPU here)
+        const uint64_t cap = (((r1 - r0) * bpr256) >> 8) + (r1 - r0) + 64 * 4096 + 65536;
+        struct Free {
+            Slot &s;
+            ~Free() { for (int i = 0; i < 2; ++i) { free(s.h_val[i].p); free(s.h_len[i].p); s.h_val[i].p = s.h_len[i].p = nullptr; s.h_val[i].cap = s.h_len[i].cap = 0; } }
+        } fr{sl};
+        for (int i = 0; i < 2; ++i) {
+            sl.h_val[i].p = malloc(cap); sl.h_val[i].cap = cap;
+            sl.h_len[i].p = malloc(r1 - r0 + 64); sl.h_len[i].cap = r1 - r0 + 64;
+        }
+        uint64_t b[2] = {bpr256, bpr256};
+        if (!pack_slice_onepass(col, r0, r1, sl, b, threads ? threads : 1)) return 0;
+        if (sl.bytes[0] > val_cap) fail("test buffer too small");
+        for (int k = 0; k < sl.nseg[0]; ++k)
+            memcpy(val_out + sl.seg_dst[0][k], static_cast<const uint8_t *>(sl.h_val[0].p) + sl.seg_src[0][k], sl.seg_bytes[0][k]);
+        memcpy(len_out, sl.h_len[0].p, r1 - r0);
+        if (bytes_out) *bytes_out = sl.bytes[0];
+        if (nseg_out) *nseg_out = sl.nseg[0];
+        // both "columns" are the same series: their segments must agree
+        if (sl.bytes[1] != sl.bytes[0] || sl.nseg[1] != sl.nseg[0]) fail("the two columns of the slice disagree");
+        return 1;
     } catch (const PluginError &e) {
         g_plugin_error = e.msg;
     } catch (...) {

@@ -211,6 +211,42 @@ __global__ void k_patch_indirect(double *__restrict__ out, uint64_t row_base, co
         out[row_base + rows[i]] = vals[i];
 }
 
+// The root of a gather in ONE launch: segment r of the receive buffer (blockIdx.y) holds rank r's codes -- packed (bits per
+// code) or 16-bit -- and, code_bytes into the segment, its exception block (count | rows | values, cap entries); rows
+// r * chunk .. of `out` are decoded and the exceptions written over the rows the codes escaped (disjoint rows: no order between
+// the two is needed).  Replaces one decode + one patch launch per peer and column.
+__global__ void k_decode_gathered(const uint8_t *__restrict__ buf, uint64_t stride, uint32_t nseg, uint64_t chunk, uint64_t last_rows,
+                                  uint32_t packed, uint32_t per, uint32_t bits, unsigned long long magic, uint64_t code_bytes,
+                                  uint32_t cap, double *__restrict__ out, const double *__restrict__ table, uint32_t *__restrict__ overflow)
+{
+    const uint32_t seg = blockIdx.y;
+    const uint8_t *base = buf + (uint64_t)seg * stride;
+    const uint64_t n = seg + 1u == nseg ? last_rows : chunk;
+    double *o = out + (uint64_t)seg * chunk;
+    if (packed) {
+        const unsigned long long *words = reinterpret_cast<const unsigned long long *>(base);
+        const unsigned long long esc = (1ull << bits) - 1ull;
+        for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t w = __umul64hi(i, magic);
+            const uint32_t j = (uint32_t)(i - w * per);
+            const unsigned long long code = (words[w] >> (j * bits)) & esc;
+            if (code != esc) o[i] = table[code];
+        }
+    } else {
+        const uint16_t *codes = reinterpret_cast<const uint16_t *>(base);
+        for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+            const uint16_t c = codes[i];
+            if (c != 0xFFFFu) o[i] = table[c];
+        }
+    }
+    const uint32_t count = *reinterpret_cast<const uint32_t *>(base + code_bytes);
+    const uint32_t *rows = reinterpret_cast<const uint32_t *>(base + code_bytes + 16u);
+    const double *vals = reinterpret_cast<const double *>(base + code_bytes + 16u + 4ull * cap);
+    if (count > cap && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1u);
+    const uint32_t m = count < cap ? count : cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) o[rows[i]] = vals[i];
+}
+
 // ---- offsets from lengths -------------------------------------------------------------------------------------------
 // The host ships a column's string LENGTHS as one byte per row (strings of at most 255 bytes) instead of its u32 offsets --
 // 35 instead of 41 bytes per pair over PCIe for cfg2's lengths -- and the offsets are rebuilt here: offsets[0] = 0,
@@ -307,6 +343,22 @@ unsigned grid_for(uint64_t n)
 }
 
 } // namespace
+
+// ---- segment compaction (strsim_compact_segments): one workgroup column per segment, 16 bytes per lane and step ----------------
+struct CompactArgs {
+    uint64_t src_off[STRSIM_COMPACT_MAX_SEGMENTS], dst_off[STRSIM_COMPACT_MAX_SEGMENTS], bytes[STRSIM_COMPACT_MAX_SEGMENTS];
+};
+__global__ __launch_bounds__(256) void k_compact_segments(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, CompactArgs a)
+{
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t k = blockIdx.y;
+    const uint8_t *s = src + a.src_off[k];
+    uint8_t *d = dst + a.dst_off[k];
+    const uint64_t n = a.bytes[k], n16 = n & ~(uint64_t)15;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u; i < n16; i += (uint64_t)gridDim.x * 256u * 16u)
+        *reinterpret_cast<u32x4_u *>(d + i) = *reinterpret_cast<const u32x4_u *>(s + i);
+    if (blockIdx.x == 0u && threadIdx.x < (uint32_t)(n - n16)) d[n16 + threadIdx.x] = s[n16 + threadIdx.x];
+}
 
 extern "C" {
 
@@ -412,6 +464,20 @@ int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint64_t row_bas
     return STRSIM_OK;
 }
 
+int strsim_compact_segments(strsim_ctx_t *ctx, const uint8_t *src, uint8_t *dst, const uint64_t *src_off,
+                                     const uint64_t *dst_off, const uint64_t *bytes, int nseg)
+{
+    if (!ctx || !src || !dst || nseg < 0 || nseg > STRSIM_COMPACT_MAX_SEGMENTS) { set_error("strsim_compact_segments: NULL buffer or more than %d segments", STRSIM_COMPACT_MAX_SEGMENTS); return STRSIM_ERR_ARG; }
+    if (nseg == 0) return STRSIM_OK;
+    CompactArgs a{};
+    uint64_t mx = 0;
+    for (int k = 0; k < nseg; ++k) { a.src_off[k] = src_off[k]; a.dst_off[k] = dst_off[k]; a.bytes[k] = bytes[k]; mx = std::max<uint64_t>(mx, bytes[k]); }
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((mx + 4095) / 4096, 1), 1024);
+    hipLaunchKernelGGL(k_compact_segments, dim3(gx, (unsigned)nseg), dim3(256), 0, (hipStream_t)strsim_ctx_stream(ctx), src, dst, a);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
 int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets)
 {
     if (!ctx || !offsets || (!lengths && rows)) { set_error("strsim_offsets_from_lengths: NULL argument"); return STRSIM_ERR_ARG; }
@@ -435,6 +501,27 @@ int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint6
     if (rc) return rc;
     hipLaunchKernelGGL(k_len_block_sums, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums);
     hipLaunchKernelGGL(k_len_offsets, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums, offsets);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_codec_decode_gathered(strsim_ctx_t *ctx, const strsim_codec_t *c, const void *buf, uint64_t seg_stride_bytes,
+                                 uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed, uint64_t code_bytes,
+                                 uint32_t exc_cap, double *out, uint32_t *overflow)
+{
+    if (!ctx || !c || !buf || !out || !overflow || nseg == 0) { set_error("strsim_codec_decode_gathered: NULL argument"); return STRSIM_ERR_ARG; }
+    if ((reinterpret_cast<uintptr_t>(buf) & 7u) || (seg_stride_bytes & 7u) || (code_bytes & 15u)) {
+        set_error("strsim_codec_decode_gathered: the buffer and the segment stride must be 8-byte, code_bytes 16-byte aligned");
+        return STRSIM_ERR_ARG;
+    }
+    if (nseg > 65535u || (chunk_rows >> 32) || (last_rows >> 32)) { set_error("strsim_codec_decode_gathered: too many segments / rows"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    const uint32_t bits = strsim_codec_bits(c), per = 64u / bits;
+    const unsigned long long magic = ~0ull / per + 1ull;
+    const uint64_t mx = std::max<uint64_t>(chunk_rows, last_rows);
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((mx + 255) / 256, 1), 4096);
+    hipLaunchKernelGGL(k_decode_gathered, dim3(gx, nseg), dim3(256), 0, st, static_cast<const uint8_t *>(buf), seg_stride_bytes, nseg,
+                       chunk_rows, last_rows, packed ? 1u : 0u, per, bits, magic, code_bytes, exc_cap, out, c->d_table, overflow);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

@@ -55,6 +55,9 @@
 #ifndef STRSIM_STAGE_RANGE_MIN_BLOCKS
 #define STRSIM_STAGE_RANGE_MIN_BLOCKS 2 // ... and at least this many blocks (1: a 3 M-row call 132 us instead of 102, cfg2 +2 %: the counter is one contended address)
 #endif
+#ifndef STRSIM_STAGE_DIVIDE
+#define STRSIM_STAGE_DIVIDE 0 // 1: Levenshtein's 1 - dist / den divides in the store phase instead of reading the quotient table
+#endif
 #ifndef STRSIM_STAGE_PRIO
 #define STRSIM_STAGE_PRIO 1
 #endif
@@ -531,7 +534,17 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
                 // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
                 // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
+#if STRSIM_STAGE_DIVIDE
+                // (variant: the division itself -- no dependent global load in the store phase, ~20 more vector instructions per
+                //  64 rows; code = dist * QTAB_N + den)
+                {
+                    const uint32_t c = (uint32_t)pk[q] == 0xFFFFu ? 1u : (uint32_t)pk[q];
+                    const uint32_t dist = c / (uint32_t)QTAB_N, den = c - dist * (uint32_t)QTAB_N;
+                    t0[q] = (double)dist / (double)(den ? den : 1u);
+                }
+#else
                 t0[q] = qtab[(uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q]];
+#endif
             } else if (JARO_LIKE) {
                 const uint32_t lo = (uint32_t)pk[q], hi = (uint32_t)(pk[q] >> 32);
                 const uint32_t m = (lo >> (ALL ? 6 : 0)) & 63u, t = (lo >> (ALL ? 12 : 6)) & 63u;

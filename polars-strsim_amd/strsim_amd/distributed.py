@@ -175,15 +175,23 @@ class ShardGatherer:
                             d0 = torch.cuda.Event(enable_timing=True)
                             d0.record(self.decode)
                         rc = self.recv_codes[b].to(self.dev) if self.host else self.recv_codes[b]
-                        for r, (off, ln) in enumerate(self.parts):  # every rank coded its own shard: decode them one by one
-                            seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes]
-                            dst = self.recv[off:off + ln]
-                            if self.packed:
-                                codec.decode_packed(seg[:self.code_bytes].view(torch.int64), ln, dst, ctx=self.ctx_decode)
-                            else:
-                                codec.decode(seg[:2 * ln].view(torch.int16), dst, ctx=self.ctx_decode)
-                            codec.patch_indirect(self.recv, off, self._exc_views(seg, self.code_bytes), self.overflow,
-                                                 ctx=self.ctx_decode)
+                        chunk = self.parts[0][1]
+                        if all(off == r * chunk for r, (off, _ln) in enumerate(self.parts)) and \
+                                all(ln == chunk for _o, ln in self.parts[:-1]) and self.ship_bytes % 8 == 0:
+                            # every rank coded its own shard; the shards are split_offsets' (equal, the last one longer): ONE launch
+                            # decodes all segments and writes their exception blocks in
+                            codec.decode_gathered(rc, self.ship_bytes, self.world, chunk, self.parts[-1][1], self.packed, self.code_bytes,
+                                                  self.exc_ship, self.recv, self.overflow, ctx=self.ctx_decode)
+                        else:
+                            for r, (off, ln) in enumerate(self.parts):  # any other partition: segment by segment
+                                seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes]
+                                dst = self.recv[off:off + ln]
+                                if self.packed:
+                                    codec.decode_packed(seg[:self.code_bytes].view(torch.int64), ln, dst, ctx=self.ctx_decode)
+                                else:
+                                    codec.decode(seg[:2 * ln].view(torch.int16), dst, ctx=self.ctx_decode)
+                                codec.patch_indirect(self.recv, off, self._exc_views(seg, self.code_bytes), self.overflow,
+                                                     ctx=self.ctx_decode)
                         self.decoded[b] = torch.cuda.Event(enable_timing=self.timing)
                         self.decoded[b].record(self.decode)
                         if self.timing:

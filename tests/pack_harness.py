@@ -27,6 +27,9 @@ def lib():
         L._strsim_test_validity.restype = C.c_int
         L._strsim_test_validity.argtypes = [C.POINTER(H.SeriesExport), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
                                             C.POINTER(C.c_uint64), C.c_uint]
+        L._strsim_test_pack_onepass.restype = C.c_int
+        L._strsim_test_pack_onepass.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p,
+                                                C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L._polars_plugin_get_last_error_message.restype = C.c_char_p
         _lib = L
     return _lib
@@ -53,6 +56,28 @@ def pack_series(x, layout="vu", r0=0, r1=None, threads=1):
         raise H.PluginError(L._polars_plugin_get_last_error_message().decode())
     assert ex.released == 1 and ex.arrays_released()
     return off, val[: used.value], valid[: max(r1 - r0, 0)].astype(bool), rows.value
+
+
+def pack_onepass(x, r0, r1, bytes_per_row, threads=1):
+    """The one-pass packer on a view column: -> None when it gives up (overflow / a string beyond 255 bytes), else
+    (lengths u8[r1 - r0], values u8 closed up, segments)."""
+    L = lib()
+    chunks, dtype = H._chunks(x, "vu")
+    ex = H._Exported("col", chunks, dtype)
+    se = H.SeriesExport()
+    ex.fill(se)
+    n = r1 - r0
+    val = np.zeros(n * 256 + 4096, dtype=np.uint8)
+    lens = np.zeros(n + 64, dtype=np.uint8)
+    used, nseg = C.c_uint64(), C.c_int()
+    rc = L._strsim_test_pack_onepass(C.byref(se), r0, r1, int(bytes_per_row * 256), threads, val.ctypes.data, val.size,
+                                     lens.ctypes.data, C.byref(used), C.byref(nseg))
+    assert ex.released == 1 and ex.arrays_released()
+    if rc < 0:
+        raise H.PluginError(L._polars_plugin_get_last_error_message().decode())
+    if rc == 0:
+        return None
+    return lens[:n], val[: used.value], nseg.value
 
 
 def validity(a, b, layouts=("vu", "vu"), threads=1, vals=None):

@@ -587,3 +587,41 @@ def test_stream_ordered_context_completes_in_stream_order(S):
         ctx.synchronize()
         assert ctx.last_late_rows == 0
     torch.cuda.synchronize()
+
+
+def test_compact_segments(S, ctx):
+    """strsim_compact_segments: the device side of the plugin's one-pass packer -- segments at arbitrary byte offsets and of
+    arbitrary byte lengths (unaligned heads and tails) moved to their final places in one launch."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, 6_000_000, dtype=np.uint8)
+    sizes = [0, 1, 15, 16, 17, 4095, 1_000_003, 999_999, 123_457, 64, 2_000_001]
+    src_off, dst_off, pos, dpos = [], [], 5, 0
+    for sz in sizes:
+        src_off.append(pos)
+        dst_off.append(dpos)
+        pos += sz + int(rng.integers(0, 5000))
+        dpos += sz
+    assert pos <= src.size
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.zeros(dpos + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    arr = lambda v: np.asarray(v, dtype=np.uint64)
+    so, do, by = arr(src_off), arr(dst_off), arr(sizes)
+    rc = S.lib().strsim_compact_segments(ctx._h, d_src.data_ptr(), d_dst.data_ptr(), so.ctypes.data, do.ctypes.data, by.ctypes.data, len(sizes))
+    assert rc == 0
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    exp = np.concatenate([src[o:o + sz] for o, sz in zip(src_off, sizes)])
+    got = d_dst.cpu().numpy()
+    assert np.array_equal(got[:dpos], exp) and not got[dpos:].any()
+    assert S.lib().strsim_compact_segments(ctx._h, d_src.data_ptr(), d_dst.data_ptr(), so.ctypes.data, do.ctypes.data, by.ctypes.data, 33) != 0
+
+
+def test_offsets_from_lengths_refuses_rows_that_could_wrap(S, ctx):
+    import torch
+    rows = 16_843_010  # one more than floor((2^32 - 1) / 255)
+    d = torch.zeros(rows, dtype=torch.uint8, device="cuda")
+    with pytest.raises(S.StrsimError, match="at most"):
+        ctx.offsets_from_lengths(d)

@@ -103,3 +103,24 @@ def test_output_validity_is_the_and_of_the_inputs(threads):
             assert (got == np.array([y is not None for y in B])).all()
             got, nulls = H.validity(ca, None, threads=threads)
             assert not got.any() and nulls == n
+
+
+@pytest.mark.parametrize("threads", [1, 4, 8])
+def test_one_pass_packer(threads):
+    """pack_slice_onepass: per-thread segments sized from a bytes-per-row budget, one length byte per row, no size pass -- equal
+    to the plain-Python packing when the budget holds, a clean "no" when a segment overflows or a string exceeds 255 bytes."""
+    rng = random.Random(12)
+    A, _ = gen.pairs(55, 70_000, gen.ASCII_LOWER, 0, 40)  # > 12 bytes: out-of-line views too
+    A = [None if rng.random() < 0.05 else x for x in A]
+    x = pa.chunked_array([pa.array(A[:20_001], type=pa.string()), pa.array(A[20_001:], type=pa.string())])
+    for r0, r1 in ((0, len(A)), (1234, 66_000)):
+        eo, ev, _ = expected(A, r0, r1)
+        got = H.pack_onepass(x, r0, r1, bytes_per_row=24, threads=threads)
+        assert got is not None
+        lens, val, nseg = got
+        assert nseg == min(threads, max((r1 - r0) // 16384, 1))
+        assert (lens == np.diff(eo).astype(np.uint8)).all() and (val == ev).all()
+    assert H.pack_onepass(x, 0, len(A), bytes_per_row=2, threads=threads) is None        # the budget does not hold
+    B = list(A)
+    B[40_000] = "q" * 300
+    assert H.pack_onepass(pa.array(B, type=pa.string()), 0, len(B), bytes_per_row=24, threads=threads) is None  # > 255 bytes
