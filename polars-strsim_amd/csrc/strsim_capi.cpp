@@ -525,7 +525,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         la.publish_host = c->status_host_dev + slot;
         hipError_t e0 = launch_lane_only(measure, la);
         if (e0 != hipSuccess) return hip_fail(e0, "kernel launch");
-        c->enqueued_ops += 1u;
+        c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la);
         HIP_TRY(hipStreamSynchronize(c->stream));
         const uint32_t left = *reinterpret_cast<volatile uint32_t *>(&c->status_host[slot].lane_left);
         if (getenv("STRSIM_TRACE")) fprintf(stderr, "[strsim] eager call: %llu rows, %u left behind the lane kernel\n", (unsigned long long)n, left);
@@ -559,7 +559,8 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         e = all ? launch_pairs_all(la, outs, c->slowmask[mb] + nchunks) : launch_pairs(measure, la);
     }
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    c->enqueued_ops += defer ? 1u : (all ? 22u : 5u); // lane kernel | + three slow-row kernels (x 5, + 5 mask copies) + status copy
+    // lane kernel (+ k_publish_lit behind k_lane_lit) | + three slow-row kernels (x 5, + 5 mask copies) + status copy
+    c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la) + (defer ? 0u : (all ? 21u : 4u));
     c->slot_timed[slot] = c->timing;
     c->slot_deferred[slot] = defer;
     c->slot_args[slot] = la;

@@ -72,9 +72,11 @@ hipError_t launch_slow_only(int measure, const LaunchArgs &a);
 // the same two halves of launch_pairs_all
 hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5]);
 hipError_t launch_slow_all_only(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);
-// does a call of `measure` (STRSIM_NUM_MEASURES = all five) with these arguments start with k_lane_stage (whose last workgroup
-// can report lane_left and the ticket)?  Not when a literal takes k_lane_lit, not on the k_lane_pairs A/B path.
+// does a call of `measure` (STRSIM_NUM_MEASURES = all five) with these arguments start with a kernel whose last workgroup reports
+// lane_left and the ticket (k_lane_stage, k_lane_stage_all, k_lane_lit)?  Not on the k_lane_pairs A/B path.
 bool lane_kernel_reports(int measure, const LaunchArgs &a);
+// launches the first kernel of such a call takes: 1, or 2 when a literal takes k_lane_lit (+ k_publish_lit behind it)
+int lane_kernel_launches(int measure, const LaunchArgs &a);
 
 // All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
 hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);

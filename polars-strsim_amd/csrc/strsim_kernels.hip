@@ -1850,7 +1850,8 @@ static void launch_lane_t(const LaunchArgs &a)
         const uint64_t gl = nlb < want ? nlb : want;
         hipLaunchKernelGGL((k_lane_lit<M>), dim3((unsigned)gl), dim3(LIT_BLOCK), 0, a.stream, litA ? a.offB : a.offA,
                            litA ? a.valB : a.valA, litA ? a.offA : a.offB, litA ? a.valA : a.valB, a.out, a.n, a.slowmask,
-                           a.status, a.qtab);
+                           a.status, a.qtab, a.sched);
+        if (a.publish_host) hipLaunchKernelGGL(k_publish_lit, dim3(1), dim3(64), 0, a.stream, a.sched, a.publish_host, a.publish_ticket);
     } else if (a.stage_grid > 0) {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
@@ -1999,13 +2000,19 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     return launch_slow_all_only(a, outs, mask_backup);
 }
 
+int lane_kernel_launches(int measure, const LaunchArgs &a)
+{
+    if (a.stage_grid <= 0 || measure == 5) return 1;
+    const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
+    const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
+    return (lit_path && !a.no_literal_path) ? 2 : 1; // k_lane_lit + k_publish_lit
+}
+
 bool lane_kernel_reports(int measure, const LaunchArgs &a)
 {
     if (a.stage_grid <= 0) return false;
-    if (measure == 5) return true; // the five-output pass has no literal kernel
-    const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
-    const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
-    return !(lit_path && !a.no_literal_path);
+    (void)measure;
+    return true; // k_lane_stage / k_lane_stage_all report themselves, k_lane_lit through k_publish_lit (only the k_lane_pairs A/B path does not)
 }
 
 hipError_t launch_lane_only(int measure, const LaunchArgs &a)

@@ -67,7 +67,7 @@ template <int MEASURE>
 __global__ __launch_bounds__(LIT_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_LIT_WAVES_PER_EU))) void
 k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, const uint32_t *__restrict__ offL,
            const uint8_t *__restrict__ valL, double *__restrict__ out, uint64_t n, unsigned long long *__restrict__ slowmask,
-           DevStatus *__restrict__ status, const double *__restrict__ qtab)
+           DevStatus *__restrict__ status, const double *__restrict__ qtab, uint32_t *__restrict__ sched)
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     constexpr bool JARO_LIKE = MEASURE == JARO || MEASURE == JARO_WINKLER;
@@ -77,8 +77,10 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
     __shared__ uint16_t s_code[LEV ? 2 : 1][LEV ? B : 1];  // Levenshtein: index into the quotient table
     __shared__ uint32_t s_word[LEV ? 1 : 2][LEV ? 1 : B];  // the other measures: their integers (stage_ints' packing)
     __shared__ uint32_t s_lit[8];
+    __shared__ uint32_t s_left; // rows of this workgroup's blocks that stay in the mask (reported like k_lane_stage does)
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    if (tid == 0u) s_left = 0u;
     if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
 #pragma unroll
     for (int q = 0; q < 2 * RPT; ++q) { // both buffers
@@ -113,7 +115,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
     const uint64_t chunk_lo = (uint64_t)blockIdx.x * per < nchunks ? (uint64_t)blockIdx.x * per : nchunks;
     const uint64_t chunk_hi = chunk_lo + per < nchunks ? chunk_lo + per : nchunks;
     const uint64_t row_end = chunk_hi * 64u < n ? chunk_hi * 64u : n;
-    if (chunk_lo * 64u >= row_end) return; // (uniform: before any further barrier)
+    if (chunk_lo * 64u < row_end) { // (uniform; a workgroup without rows still reports below)
 
     const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0][0]), ldsOff = STRSIM_LDS_ADDR(&s_off[0][0]);
     const uint32_t wvu = uniform(wv), tid4 = tid * 4u, tid16 = tid * 16u;
@@ -197,7 +199,10 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
                 else if (!undone) v = stage_epilogue<M1>(pk[q], t0[q], t1[q], t2[q]);
                 const unsigned long long left = __ballot(undone && valid);
                 if (valid && !undone) outb[i] = v;
-                if (lane == 0u && valid) maskb[i >> 6] = left;
+                if (lane == 0u && valid) {
+                    maskb[i >> 6] = left;
+                    if (left) atomicAdd(&s_left, (uint32_t)__builtin_popcountll(left));
+                }
             }
         }
     };
@@ -305,4 +310,21 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
     }
     lds_barrier();
     store_block(prev_row0, prev_rows, prev_bb);
+    } // (this workgroup's rows)
+    // Rows this workgroup left in the mask -> sched[2] (relaxed: k_publish_lit reads the sum behind this kernel, in stream order).
+    // No "last workgroup" protocol here, unlike k_lane_stage: this kernel's many short-lived workgroups would each have to drain
+    // their result stores before signalling (a release per workgroup: measured +7 % on the kernel); the end of the kernel does that
+    // for free.
+    lds_barrier();
+    if (tid == 0u && s_left) __hip_atomic_fetch_add(&sched[2], s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// behind k_lane_lit: lane_left (and, for a call that consists of that kernel alone, the ticket) to the host-mapped status block
+__global__ void k_publish_lit(uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
+{
+    if (threadIdx.x != 0u) return;
+    const uint32_t total = __hip_atomic_load(&sched[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sched[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&publish->lane_left, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ticket) __hip_atomic_store(&publish->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

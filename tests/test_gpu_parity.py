@@ -625,3 +625,29 @@ def test_offsets_from_lengths_refuses_rows_that_could_wrap(S, ctx):
     d = torch.zeros(rows, dtype=torch.uint8, device="cuda")
     with pytest.raises(S.StrsimError, match="at most"):
         ctx.offsets_from_lengths(d)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("side", ["a", "b"])
+def test_literal_calls_are_one_launch_too(S, measure, side):
+    """A column of short ASCII strings against a literal is k_lane_lit + a one-thread kernel that publishes what it left (two
+    launches instead of six) on a context that expects no slow rows -- Jaro / Jaro-Winkler with a literal b run in k_lane_stage:
+    one launch; a literal the lane kernels cannot take (longer than 32 bytes) is finished at retirement."""
+    import torch
+    A, B, cols = _mixed_frame(S, 0)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    for lit in ("phillips", "q" * 40):
+        lo, lv = S.pack_strings([lit])
+        lcols = (t(lo, np.int32), t(np.concatenate([lv, pad]), np.uint8))
+        torch.cuda.synchronize()
+        with S.Context(0) as ctx:
+            before = ctx.enqueued_ops
+            out = ctx.pairs_device(measure, *(lcols + cols[:2] if side == "a" else cols[:2] + lcols))
+            assert ctx.enqueued_ops - before == (1 if (measure in ("jaro", "jaro_winkler") and side == "b") else 2)
+            ctx.synchronize()
+            assert (ctx.last_late_rows == 0) == (len(lit) <= 32)
+            exp = O.batch_strings(measure, [lit] * len(A) if side == "a" else A, A if side == "a" else [lit] * len(A), 8)
+            assert_bit_exact(out.cpu().numpy(), exp, [lit] * len(A) if side == "a" else A, A if side == "a" else [lit] * len(A),
+                             "literal %s, %s" % (side, measure))
