@@ -651,3 +651,59 @@ def test_literal_calls_are_one_launch_too(S, measure, side):
             exp = O.batch_strings(measure, [lit] * len(A) if side == "a" else A, A if side == "a" else [lit] * len(A), 8)
             assert_bit_exact(out.cpu().numpy(), exp, [lit] * len(A) if side == "a" else A, A if side == "a" else [lit] * len(A),
                              "literal %s, %s" % (side, measure))
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_gathered_segments_decode_in_one_launch(S, packed):
+    """strsim_codec_decode_gathered (the root's side of the gather): three ranks' segments -- codes + exception block each, the
+    last shard longer, as split_offsets cuts them -- decoded by ONE launch == the per-segment decode + patch."""
+    import torch
+    measure = "levenshtein" if packed else "jaro"
+    A, B = gen.pairs(81, 30_000, gen.ASCII_LOWER, 0, 32, max_bytes=32)
+    A2, B2 = gen.pairs(82, 41, gen.ASCII_LOWER, 40, 120)  # outside the table: exceptions
+    A, B = A[:10_000] + A2[:20] + A[10_000:] + A2[20:], B[:10_000] + B2[:20] + B[10_000:] + B2[20:]
+    n = len(A)
+    parts = S.split_offsets(n, 3)
+    chunk, last = parts[0][1], parts[-1][1]
+    oa, va = S.pack_strings(A)
+    ob, vb = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    torch.cuda.synchronize()
+    with S.Context(0) as ctx:
+        vals = ctx.pairs_device(measure, t(oa, np.int32), t(np.concatenate([va, pad]), np.uint8), t(ob, np.int32),
+                                t(np.concatenate([vb, pad]), np.uint8))
+        ctx.synchronize()
+        codec = S.Codec(ctx, measure, 32)
+        assert (64 // codec.bits > 4) == packed
+        cap = 256
+        code_bytes = ((8 * codec.packed_words(last) if packed else 2 * last) + 15) & ~15
+        stride = code_bytes + 16 + 12 * cap
+        buf = torch.zeros(3 * stride, dtype=torch.uint8, device=dev)
+        nexc = []
+        for r, (off, ln) in enumerate(parts):
+            seg = buf[r * stride:(r + 1) * stride]
+            exc = (seg[code_bytes:code_bytes + 4].view(torch.int32), seg[code_bytes + 16:code_bytes + 16 + 4 * cap].view(torch.int32),
+                   seg[code_bytes + 16 + 4 * cap:code_bytes + 16 + 12 * cap].view(torch.float64))
+            if packed:
+                codec.encode_packed(vals[off:off + ln], seg[:code_bytes].view(torch.int64), exc=exc)
+            else:
+                codec.encode(vals[off:off + ln], seg[:2 * ln].view(torch.int16), exc=exc)
+            ctx.synchronize()
+            nexc.append(int(exc[0].item()))
+        assert sum(nexc) >= 30 and max(nexc) <= cap
+        out = torch.full((n,), -1.0, dtype=torch.float64, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        codec.decode_gathered(buf, stride, 3, chunk, last, packed, code_bytes, cap, out, overflow)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert int(overflow.item()) == 0
+        assert torch.equal(out.view(torch.int64), vals.view(torch.int64))
+        # a block that holds fewer exceptions than its rank had: the overflow flag, not silence
+        codec.decode_gathered(buf, stride, 3, chunk, last, packed, code_bytes, 4, out, overflow)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert int(overflow.item()) >= 1
+        codec.close()
