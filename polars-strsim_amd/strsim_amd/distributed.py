@@ -74,6 +74,10 @@ class ShardGatherer:
         import strsim_amd as S
         if ctx.stream != compute_stream.cuda_stream:
             raise ValueError("ShardGatherer: ctx does not enqueue on compute_stream")
+        # shipments read a step's results behind an event on the compute stream, without retiring the call first: every kernel of
+        # a call must be on the stream when submit() is called (strsim_ctx_set_stream_ordered; one-launch calls would finish slow
+        # rows only at synchronize())
+        ctx.set_stream_ordered(True)
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.parts = list(parts) if parts is not None else [(r * rows, rows) for r in range(self.world)]
         if len(self.parts) != self.world:
