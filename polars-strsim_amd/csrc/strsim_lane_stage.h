@@ -55,6 +55,9 @@
 #ifndef STRSIM_STAGE_RANGE_MIN_BLOCKS
 #define STRSIM_STAGE_RANGE_MIN_BLOCKS 2 // ... and at least this many blocks (1: a 3 M-row call 132 us instead of 102, cfg2 +2 %: the counter is one contended address)
 #endif
+#ifndef STRSIM_STAGE_ALIAS
+#define STRSIM_STAGE_ALIAS 0 // experiment (with tables): every window of the block is fetched first, then -- behind one more barrier --
+#endif                       // the tables live in the staging area (no LDS of their own: room for larger blocks at 4 workgroups per CU)
 #ifndef STRSIM_STAGE_DIVIDE
 #define STRSIM_STAGE_DIVIDE 0 // 1: Levenshtein's 1 - dist / den divides in the store phase instead of reading the quotient table
 #endif
@@ -382,13 +385,15 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
     constexpr bool MLUT = !LUT && stage_uses_mlut<MEASURE>();
     // The 1 KB behind each wave's tables holds 128 of the block's row descriptors (without tables: an array of their own).
-    static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
+    static_assert(!LUT || STRSIM_STAGE_ALIAS != 0 || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
     // (the small table: 1 KB per wave at a 1 KB boundary)
-    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : (MLUT ? MLUT_WAVE_BYTES * STAGE_WAVES : 16)];
-    __shared__ uint2 s_desc_own[LUT ? 1 : B];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[2 * STAGE_COL + 64];
+    constexpr bool ALIAS = LUT && STRSIM_STAGE_ALIAS != 0;
+    static_assert(!ALIAS || 4096 * STAGE_WAVES <= 2 * STAGE_COL, "aliased tables lie inside the staging area");
+    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[(LUT && !ALIAS) ? 4096 * STAGE_WAVES : (MLUT ? MLUT_WAVE_BYTES * STAGE_WAVES : 16)];
+    __shared__ uint2 s_desc_own[(LUT && !ALIAS) ? 1 : B];
+    __shared__ __attribute__((aligned(4096))) uint8_t s_bytes[2 * STAGE_COL + 64];
     auto desc_at = [&](uint32_t p) -> uint2 * { // descriptor of position p of the length order
-        if (LUT) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
+        if (LUT && !ALIAS) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
         return s_desc_own + p;
     };
     __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 4]; // offsets of the rows from the next block's start on
@@ -472,7 +477,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 
     EqLut lut; // this wave's match-mask tables
     lut.lane4 = lane * 4u;
-    lut.krep = ((STRSIM_LDS_ADDR(&s_lut[0]) >> 8) + (LUT ? 16u : 4u) * wv) * 0x01010101u;
+    lut.krep = ((STRSIM_LDS_ADDR(ALIAS ? &s_bytes[0] : &s_lut[0]) >> 8) + (LUT ? 16u : 4u) * wv) * 0x01010101u;
     const uint32_t ldsOffA = STRSIM_LDS_ADDR(&s_off[0][0]), ldsOffB = STRSIM_LDS_ADDR(&s_off[1][0]);
     const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0]);
     const uint32_t wvu = uniform(wv);
@@ -750,34 +755,66 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #if STRSIM_STAGE_PRIO
         __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
 #endif
-#pragma unroll 1
-        for (int k = 0; k < STAGE_RPW; ++k) {
-            const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
-#ifdef STRSIM_EXP_NOSORT
-            if (r * 64u >= rows) continue;
-#else
-            if (r * 64u >= nmine) continue;
-#endif
-#ifdef STRSIM_EXP_NOROUNDS
-            if (nmine != 0x12345u) continue;
-#endif
+        if constexpr (ALIAS) {
+            // every window of the block into registers first, one more barrier, then the staging area holds the tables
+            uint32_t meta[STAGE_RPW];
+            uint32_t wts[STAGE_RPW][8], wps[STAGE_RPW][8];
+            bool run[STAGE_RPW];
 #if STRSIM_STAGE_PRIO_WINDOWS
             __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
 #endif
-            const uint2 d = *desc_at(r * 64u + lane);
-            uint32_t wt[8], wp[8];
-            stage_window(s_bytes, d.x & 0xFFFFu, wt);
-            stage_window(s_bytes, d.x >> 16, wp);
-#if defined(STRSIM_STAGE_STAMPS) || defined(STRSIM_STAGE_LGKM)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+#pragma unroll
+            for (int k = 0; k < STAGE_RPW; ++k) {
+                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+                run[k] = r * 64u < nmine;
+                if (run[k]) {
+                    const uint2 d = *desc_at(r * 64u + lane);
+                    meta[k] = d.y;
+                    stage_window(s_bytes, d.x & 0xFFFFu, wts[k]);
+                    stage_window(s_bytes, d.x >> 16, wps[k]);
+                }
+            }
             STAGE_STAMP(7);
-#if STRSIM_STAGE_PRIO_WINDOWS && !STRSIM_STAGE_PRIO_PLANES
+            lds_barrier();
             __builtin_amdgcn_s_setprio(0);
-#endif
-            const uint32_t in_round = nmine - r * 64u; // (>= 1)
-            stage_compute<MEASURE, LUT>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
-            STAGE_STAMP(8);
+#pragma unroll
+            for (int k = 0; k < STAGE_RPW; ++k) {
+                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+                if (!run[k]) continue;
+                const uint32_t in_round = nmine - r * 64u; // (>= 1)
+                stage_compute<MEASURE, LUT>(lut, wts[k], wps[k], meta[k], (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
+                STAGE_STAMP(8);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < STAGE_RPW; ++k) {
+                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+    #ifdef STRSIM_EXP_NOSORT
+                if (r * 64u >= rows) continue;
+    #else
+                if (r * 64u >= nmine) continue;
+    #endif
+    #ifdef STRSIM_EXP_NOROUNDS
+                if (nmine != 0x12345u) continue;
+    #endif
+    #if STRSIM_STAGE_PRIO_WINDOWS
+                __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
+    #endif
+                const uint2 d = *desc_at(r * 64u + lane);
+                uint32_t wt[8], wp[8];
+                stage_window(s_bytes, d.x & 0xFFFFu, wt);
+                stage_window(s_bytes, d.x >> 16, wp);
+    #if defined(STRSIM_STAGE_STAMPS) || defined(STRSIM_STAGE_LGKM)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    #endif
+                STAGE_STAMP(7);
+    #if STRSIM_STAGE_PRIO_WINDOWS && !STRSIM_STAGE_PRIO_PLANES
+                __builtin_amdgcn_s_setprio(0);
+    #endif
+                const uint32_t in_round = nmine - r * 64u; // (>= 1)
+                stage_compute<MEASURE, LUT>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
+                STAGE_STAMP(8);
+            }
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
 #if STRSIM_STAGE_PRIO
