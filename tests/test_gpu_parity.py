@@ -707,3 +707,18 @@ def test_gathered_segments_decode_in_one_launch(S, packed):
         torch.cuda.synchronize()
         assert int(overflow.item()) >= 1
         codec.close()
+
+
+def test_more_calls_in_flight_than_the_ring_holds(S):
+    """70 asynchronous calls before one synchronize(): the ring of 32 status slots wraps twice and the four mask buffers are
+    reused again and again while clean frames and frames with slow rows alternate (so the context mispredicts every few
+    calls and finishes slow rows of calls that were retired on the way, not at the final synchronize)."""
+    frames = {k: _mixed_frame(S, k) for k in (0, 40)}
+    exp = {k: O.batch_strings("jaccard", f[0], f[1], 8) for k, f in frames.items()}
+    order = [0, 0, 40, 0, 40, 40, 0] * 10
+    with S.Context(0) as ctx:
+        outs = [ctx.pairs_device("jaccard", *frames[k][2]) for k in order]
+        ctx.synchronize()
+        for o, k in zip(outs, order):
+            assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "ring wrap, %d slow rows" % k)
+        assert ctx.enqueued_ops >= len(order)
