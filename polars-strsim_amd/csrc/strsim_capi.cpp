@@ -57,7 +57,7 @@ struct strsim_ctx {
     int num_cu = 0;
     int stage_wg_per_cu = 5;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pairs instead of k_lane_stage (A/B runs)
     int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
-    int lev_waves_per_cu = 19; // STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
+    int lev_waves_per_cu = 20; // five per SIMD (96 VGPRs, 6.7 KB of LDS); STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only).  The "not finished yet" masks (+ backup + work list) of a call: a ring of MASKBUFS buffers, slot s
     // uses buffer s % MASKBUFS -- a call whose slow-row kernels are launched late (below) needs its mask intact while
     // younger calls run
@@ -501,7 +501,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         la.wide_grid_cap = c->num_cu * wide_cap_per_cu;
     }
     la.wave_grid = c->num_cu * 16;                       // k_wave_pairs, other measures: 4 waves per SIMD
-    la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu; // 8 KB of LDS (match table) per wave
+    la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu;
     {   // per-wave global scratch of k_wave_pairs (scalar-value arrays; Levenshtein: text arenas as well)
         const size_t waves = (size_t)std::max(la.wave_grid, la.wave_grid_lev);
         rc = ctx_reserve((void **)&c->lev_ws, &c->lev_ws_cap, waves * LEV_WS_WORDS * sizeof(uint32_t));

@@ -17,6 +17,10 @@ constexpr int WAVE_CAP = 1024; // wave-per-pair kernels: max bytes (hence scalar
 #define STRSIM_LEV_JOBS 16
 #endif
 constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
+#ifndef STRSIM_LEV_BYTES_ROWS
+#define STRSIM_LEV_BYTES_ROWS 64 // pattern rows per lane of an ASCII batch of k_wave_pairs<levenshtein>: 64 (two mask words) or 32
+#endif
+constexpr int LEV_BYTES_ROWS = STRSIM_LEV_BYTES_ROWS;
 constexpr int TXT_PAD = 48;
 constexpr int ARENA0_BYTES = 8192;
 constexpr int ARENA1_BYTES = 12288;

@@ -932,27 +932,35 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     };
     word_t w0 = fetch(j), w1 = fetch(j + 4);
     uint32_t t = 0;
-    uint32_t *const trow = tab + lane;
+    // the split tables of strsim_lane_lut.h (12 entries, 3 KB per wave): Eq(c) = L[c & 7] & M[(c >> 3) & 3]
+    EqLut tl;
+    tl.lane4 = lane * 4u;
+    tl.krep = (STRSIM_LDS_ADDR(tab) >> 8) * 0x01010101u;
     {
         uint32_t P5[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) P5[k] = P[k];
-#pragma unroll
-        for (int code = 0; code < 32; ++code) trow[code * 64] = eq_mask<5>(P5, valid, (uint32_t)code, 0);
+        lut_build<5>(tl, P5, valid);
     }
     // column q (0..3) of the fetched word: its 32-bit half and the bit its symbol starts at
     auto half = [&](word_t w, int q) { return SYMBOLS ? (uint32_t)((uint64_t)w >> (32 * (q >> 1))) : (uint32_t)w; };
     auto bit0 = [&](int q) { return SYMBOLS ? 16 * (q & 1) : 8 * q; };
-    // mask of column q of w: table look-up on the low five bits, then the higher planes
+    // mask of column q of w: the two table entries of its low five bits, then the higher planes
     auto high_planes = [&](uint32_t e, word_t w, int q) {
 #pragma unroll
         for (int k = 5; k < NP; ++k) e = bitop3<0x90>(e, P[k], (uint32_t)__builtin_amdgcn_sbfe((int)half(w, q), bit0(q) + k, 1u));
         return e;
     };
+    auto lookup = [&](const LutIndex &ix, int q) { // ix: the table coordinates of the bytes of half(w, q)
+        const int byte = SYMBOLS ? 2 * (q & 1) : q;
+        return lut_read(tl, ix.l, byte) & lut_read(tl, ix.m, byte);
+    };
     auto trip = [&](word_t w) { // four steps on the four columns of w
         uint32_t e[4];
+        const LutIndex ix0 = lut_index(tl, half(w, 0));
+        const LutIndex ix1 = SYMBOLS ? lut_index(tl, half(w, 2)) : ix0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = trow[bfe_u32(half(w, q), (uint32_t)bit0(q), 5u) * 64u];
+        for (int q = 0; q < 4; ++q) e[q] = lookup(q < 2 ? ix0 : ix1, q);
 #pragma unroll
         for (int q = 0; q < 4; ++q) step(high_planes(e[q], w, q));
     };
@@ -968,7 +976,7 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
         trip(w0); t += 4u; w0 = w1; w1 = w2;
         if (t + 4u <= T) { trip(w0); t += 4u; w0 = w1; }
     }
-    for (; t < T; ++t, w0 >>= 8 * UNIT) step(high_planes(trow[((uint32_t)w0 & 31u) * 64u], w0, 0));
+    for (; t < T; ++t, w0 >>= 8 * UNIT) step(high_planes(lookup(lut_index(tl, (uint32_t)w0), 0), w0, 0));
     __builtin_amdgcn_s_setprio(1);
     // No running score: every block stops updating after its last column, so once all are done the column-n vertical
     // deltas are in Pv/Mv.  The row above block 0 sits at s + n (it starts at s because the s fictitious rows below it
@@ -988,6 +996,159 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     if (lane < njobs) {
         const int sum = hi_sum - (qseg ? lo_sum : 0);
         const uint32_t dist = (uint32_t)((int)(32u * qB - qm + qn) + sum);
+        out[jobs[q].row] = epilogue_levenshtein(dist, qm, qn);
+    }
+}
+
+// wave_lev_blocks for BYTES batches with SIXTY-FOUR pattern rows per lane (two mask words): what a step spends per lane
+// whatever the word holds -- the hand-off through DPP, its decoding and publishing, the column test, the table addresses --
+// is paid once per 64 cells instead of once per 32 (about 12 of the 23 instructions of the one-word step; the two-word
+// step is 30 + 3.5 for the table addresses and the text fetch: 0.7 of two one-word steps).  A job takes ceil(m / 64)
+// lanes.  The match masks come from the split tables of strsim_lane_lut.h (L[c & 7] & M[(c >> 3) & 3], 12 entries per
+// word): the 32-entry table of the one-word form would be 16 KB per wave.  Low words at tab (4 KB-aligned), high words
+// 3 KB above; one address (a v_perm_b32) serves both.  Same recurrences, hand-off and distance formula as above.
+template <int NP>
+__device__ __forceinline__ void wave_lev_blocks64(const BlockJob *jobs, uint32_t njobs, uint32_t T, const BlockCols &cols,
+                                                  const uint8_t *arena, uint32_t *tab, double *__restrict__ out)
+{
+    static_assert(NP == 5 || NP == 7, "ASCII: five tabulated planes plus 0 or 2 computed ones");
+    const uint32_t lane = lane_id();
+    uint32_t jdx = 0;
+    for (uint32_t q = 1; q < njobs; ++q) jdx += lane >= (uint32_t)jobs[q].seg ? 1u : 0u;
+    const uint32_t m = jobs[jdx].m, n = jobs[jdx].n;
+    const uint32_t blk = lane - jobs[jdx].seg;
+    const uint32_t B = (m + 63u) >> 6;
+    const bool mine = blk < B;
+    const uint32_t s = 64u * B - m; // fictitious shared-prefix rows at the bottom of block 0 (0..63)
+    uint32_t Plo[NP], Phi[NP];
+    {
+        const bool in_a = jobs[jdx].in_a != 0;
+        uint32_t w[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) w[d] = 0u;
+        if (mine)
+            load_window_any<16>(in_a ? cols.valA : cols.valB, (int64_t)jobs[jdx].p0 + (int64_t)m - 64 * (int64_t)(B - blk),
+                                in_a ? cols.totalA : cols.totalB, w);
+        uint32_t h[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) h[d] = w[d];
+        build_planes<NP>(h, Plo);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) h[d] = w[8 + d];
+        build_planes<NP>(h, Phi);
+    }
+    const uint64_t valid = blk == 0u ? ~((1ull << s) - 1ull) : ~0ull;
+    uint64_t Pv = valid, Mv = ~valid;
+    const uint32_t first = blk == 0u ? 1u : 0u;
+    const uint32_t pubw = blk + 1u == B ? 0u : 1u;
+    // Hand-off: the +1 and the -1 leaving a block's bottom row travel in two registers (one DPP move each, the +1 one
+    // fused with the OR of `first`), so neither side packs or unpacks anything.
+    uint32_t houtP = 0u, houtN = 0u;
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    const uint32_t txt0 = 4u * (uint32_t)jobs[jdx].txt + TXT_PAD; // this job's column 0 in the arena (uniform base + 32-bit offset)
+    const uint32_t ncol = mine ? n : 0u;
+    const uint32_t end = mine ? blk + n : 0u;   // first step at which this block has no column left
+    const int32_t jlast = (int32_t)n + TXT_PAD - 4;
+    uint32_t tt = 0u;                            // the step (uniform); this block's column is tt - blk
+    const uint32_t fetch0 = txt0 - blk, fetch_last = txt0 + (uint32_t)jlast; // (blk <= 15 < TXT_PAD <= txt0)
+    auto fetch = [&](uint32_t ahead) -> uint32_t { // columns tt + ahead - blk .. + 3 of this lane's text, not past its rear pad
+        const uint32_t at = tt + ahead + fetch0;
+        return *reinterpret_cast<const u32_unaligned *>(arena + (at < fetch_last ? at : fetch_last));
+    };
+    // the tables: this lane's column of the low-word table at tab, of the high-word table 3 KB above
+    EqLut tl, th;
+    tl.lane4 = th.lane4 = lane * 4u;
+    tl.krep = (STRSIM_LDS_ADDR(tab) >> 8) * 0x01010101u;
+    th.krep = ((STRSIM_LDS_ADDR(tab) >> 8) + (uint32_t)LUT_ENTRIES) * 0x01010101u;
+    lut_build<NP>(tl, Plo, (uint32_t)valid);
+    lut_build<NP>(th, Phi, (uint32_t)(valid >> 32));
+    struct Col { uint32_t llo, lhi, mlo, mhi; };
+    auto lookup = [&](const LutIndex &ix, uint32_t w, int q) {
+        const uint32_t al = __builtin_amdgcn_perm(ix.l, tl.lane4, 0x0C0C0000u | ((4u + (uint32_t)q) << 8));
+        const uint32_t am = __builtin_amdgcn_perm(ix.m, tl.lane4, 0x0C0C0000u | ((4u + (uint32_t)q) << 8));
+        Col c;
+#if defined(__HIP_DEVICE_COMPILE__)
+        c.llo = lut_lds_read(al); c.lhi = lut_lds_read(al + (uint32_t)LUT_WAVE_BYTES);
+        c.mlo = lut_lds_read(am); c.mhi = lut_lds_read(am + (uint32_t)LUT_WAVE_BYTES);
+#else
+        c.llo = c.lhi = al; c.mlo = c.mhi = am; // (host pass of hipcc: never run)
+#endif
+        if (NP > 5) {
+            c.mlo &= lut_high_planes<NP>(Plo, w, q);
+            c.mhi &= lut_high_planes<NP>(Phi, w, q);
+        }
+        return c;
+    };
+    // RAMP: the first steps, while blocks are still starting (block k runs columns from step k on); after step 16 every
+    // block has started and "has a column left" is one compare against the uniform step.
+    auto step = [&](const Col &c, auto ramp) {
+        uint32_t hinP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtP, 0x138 /* wave_shr:1 */, 0xF, 0xF, true) | first;
+        asm volatile("" : "+v"(hinP)); // keeps the OR next to the move (one v_or_b32_dpp) instead of behind the shift that uses it
+        const uint32_t hinN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtN, 0x138, 0xF, 0xF, true);
+        const bool on = decltype(ramp)::value ? (tt - blk) < ncol : tt < end;
+        if (on) {
+            const uint32_t Pvl = (uint32_t)Pv, Pvh = (uint32_t)(Pv >> 32), Mvl = (uint32_t)Mv, Mvh = (uint32_t)(Mv >> 32);
+            const uint32_t Xvl = bitop3<0xEA>(c.llo, c.mlo, Mvl), Xvh = bitop3<0xEA>(c.lhi, c.mhi, Mvh); // Eq0 | Mv
+            const uint32_t Eql = bitop3<0xEA>(c.llo, c.mlo, hinN), Eqh = c.lhi & c.mhi;                    // Eq0 | hinN
+            const uint64_t sum = (((uint64_t)(Eqh & Pvh) << 32) | (Eql & Pvl)) + Pv;
+            const uint32_t Xhl = bitop3<0xBE>((uint32_t)sum, Pvl, Eql), Xhh = bitop3<0xBE>((uint32_t)(sum >> 32), Pvh, Eqh);
+            const uint32_t Phl = bitop3<0xF1>(Mvl, Xhl, Pvl), Phh = bitop3<0xF1>(Mvh, Xhh, Pvh);
+            const uint32_t Mhl = Pvl & Xhl, Mhh = Pvh & Xhh;
+            houtP = bfe_u32(Phh, 31u, pubw);
+            houtN = bfe_u32(Mhh, 31u, pubw);
+            const uint32_t PhSl = (Phl << 1) | hinP, PhSh = (uint32_t)__builtin_amdgcn_alignbit(Phh, Phl, 31);
+            const uint32_t MhSl = (Mhl << 1) | hinN, MhSh = (uint32_t)__builtin_amdgcn_alignbit(Mhh, Mhl, 31);
+            Pv = ((uint64_t)bitop3<0xF1>(MhSh, Xvh, PhSh) << 32) | bitop3<0xF1>(MhSl, Xvl, PhSl);
+            Mv = ((uint64_t)(PhSh & Xvh) << 32) | (PhSl & Xvl);
+        }
+        ++tt;
+    };
+    uint32_t w0 = fetch(0u), w1 = fetch(4u);
+    auto trip = [&](uint32_t w, auto ramp) { // four steps on the four columns of w
+        const LutIndex ix = lut_index(tl, w);
+        Col c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = lookup(ix, w, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) step(c[q], ramp);
+    };
+    __builtin_amdgcn_s_setprio(0);
+    uint32_t w2 = fetch(8u);
+    // three words in flight, refilled in turn (before a trip, the word two trips ahead of it is the one fetched: + 8 columns)
+    const std::true_type ramp_on{};
+    const std::false_type ramp_off{};
+    for (; tt < 24u && tt + 12u <= T;) {
+        trip(w0, ramp_on); w0 = fetch(8u);
+        trip(w1, ramp_on); w1 = fetch(8u);
+        trip(w2, ramp_on); w2 = fetch(8u);
+    }
+    for (; tt + 12u <= T;) {
+        trip(w0, ramp_off); w0 = fetch(8u);
+        trip(w1, ramp_off); w1 = fetch(8u);
+        trip(w2, ramp_off); w2 = fetch(8u);
+    }
+    if (tt + 4u <= T) {
+        trip(w0, ramp_on); w0 = w1; w1 = w2;
+        if (tt + 4u <= T) { trip(w0, ramp_on); w0 = w1; }
+    }
+    for (; tt < T; w0 >>= 8) step(lookup(lut_index(tl, w0), w0, 0), ramp_on);
+    __builtin_amdgcn_s_setprio(1);
+    int pre = mine ? (int)popc32((uint32_t)Pv) + (int)popc32((uint32_t)(Pv >> 32)) - (int)popc32((uint32_t)Mv) -
+                         (int)popc32((uint32_t)(Mv >> 32))
+                   : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(pre, d);
+        if (lane >= (uint32_t)d) pre += up;
+    }
+    const uint32_t q = lane < njobs ? lane : 0u;
+    const uint32_t qseg = jobs[q].seg, qm = jobs[q].m, qn = jobs[q].n;
+    const uint32_t qB = (qm + 63u) >> 6;
+    const int hi_sum = __shfl(pre, (int)(qseg + qB - 1u));
+    const int lo_sum = __shfl(pre, (int)(qseg ? qseg - 1u : 0u));
+    if (lane < njobs) {
+        const int sum = hi_sum - (qseg ? lo_sum : 0);
+        const uint32_t dist = (uint32_t)((int)(64u * qB - qm + qn) + sum);
         out[jobs[q].row] = epilogue_levenshtein(dist, qm, qn);
     }
 }
@@ -1441,8 +1602,19 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
     return r;
 }
 
+// Five waves per SIMD: the Levenshtein step loop is one dependent chain per wave and bound by what the SIMD issues (cfg5:
+// 59.4 -> 56.0 ms against four; the compiler takes 101 VGPRs on its own, 96 with six spilled outside the step loop; six
+// waves per SIMD: 53.3 against 52.8).  The other measures fit 96 anyway and are bound by their LDS.
+#ifndef STRSIM_WAVE_WAVES_PER_EU
+#define STRSIM_WAVE_WAVES_PER_EU 5
+#endif
+#if STRSIM_WAVE_WAVES_PER_EU > 0
+#define STRSIM_WAVE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(STRSIM_WAVE_WAVES_PER_EU)))
+#else
+#define STRSIM_WAVE_OCCUPANCY
+#endif
 template <int MEASURE>
-__global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
+__global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
                                                    uint64_t rowsA, const uint32_t *__restrict__ offB,
                                                    const uint8_t *__restrict__ valB, uint64_t rowsB,
                                                    double *__restrict__ out, uint64_t n,
@@ -1473,7 +1645,11 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
     uint8_t *const g_ar1 = g_ar0 + ARENA0_BYTES;
     uint16_t *const g_pat = reinterpret_cast<uint16_t *>(g_ar1 + ARENA1_BYTES);
     __shared__ BlockJob s_job[2][LEV ? LEV_JOBS : 1];
-    __shared__ uint32_t s_tab[LEV ? 32 * 64 : 1]; // wave_lev_blocks: match masks by code (low five bits) and lane
+    // wave_lev_blocks: the split match tables of a lane (3 KB per wave); wave_lev_blocks64: one per mask word (6 KB)
+    #ifndef STRSIM_WAVE_TAB_WORDS
+#define STRSIM_WAVE_TAB_WORDS (2 * LUT_ENTRIES * 64)
+#endif
+    __shared__ __attribute__((aligned(4096))) uint32_t s_tab[LEV ? STRSIM_WAVE_TAB_WORDS : 1];
     __shared__ uint8_t s_order[64], s_blk[64];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
@@ -1493,10 +1669,15 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
             // fence of the barrier orders them before the loads below, and the CU's L1 is coherent for its own waves
             __syncthreads();
             // five planes when bits 5 and 6 are constant over every byte of the jobs (a-z), else all seven
-            if ((job_or6 ^ job_and6) & 0x60u)
-                wave_lev_blocks<7, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
-            else
-                wave_lev_blocks<5, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
+            if constexpr (LEV_BYTES_ROWS == 64) {
+                if ((job_or6 ^ job_and6) & 0x60u) wave_lev_blocks64<7>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, s_tab, out);
+                else wave_lev_blocks64<5>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, s_tab, out);
+            } else {
+                if ((job_or6 ^ job_and6) & 0x60u)
+                    wave_lev_blocks<7, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
+                else
+                    wave_lev_blocks<5, false>(s_job[0], bq0.njobs, bq0.T, cols, g_ar0, g_pat, s_tab, out);
+            }
             job_or6 = 0u; job_and6 = 0x60u;
             __syncthreads();
             bq0 = Batch{0u, 0u, 0u, 0u};
@@ -1587,7 +1768,9 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                 uint32_t bitpos = vi;
                 if (MEASURE == LEVENSHTEIN) {
                     const uint32_t need = uniform((uint32_t)s_blk[vi]); // upper bound: blocks of the shorter BYTE length
-                    if ((bq0.lanes > bq1.lanes ? bq0.lanes : bq1.lanes) + need > 64u) continue; // no room in this pass
+                    // no room in this pass (a BYTES job takes a lane per LEV_BYTES_ROWS rows, a SYMBOLS job one per 32)
+                    const uint32_t need0 = (need * 32u + (uint32_t)LEV_BYTES_ROWS - 1u) / (uint32_t)LEV_BYTES_ROWS;
+                    if (bq0.lanes + need0 > 64u || bq1.lanes + need > 64u) continue;
                     bitpos = uniform((uint32_t)s_order[vi]);
                 }
                 todo &= ~(1ull << vi);
@@ -1609,7 +1792,7 @@ __global__ __launch_bounds__(64) void k_wave_pairs(const uint32_t *__restrict__ 
                     // ---- BYTES: shorter string = DP rows (read from its column), longer = columns (staged bytes)
                     const bool a_short = la8 <= lb8;
                     const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
-                    const uint32_t Bn = (ms + 31u) >> 5;
+                    const uint32_t Bn = (ms + (uint32_t)LEV_BYTES_ROWS - 1u) / (uint32_t)LEV_BYTES_ROWS;
                     uint32_t o6 = job_or6, n6 = job_and6;
                     bool ascii = !long_bytes && wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
                     if (ascii) {
