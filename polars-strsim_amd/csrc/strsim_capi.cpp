@@ -338,6 +338,10 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         const int v = atoi(env);
         if (v >= 0 && v <= 64) c->stage_wg_per_cu = v;
     }
+    {
+        const int resident = strsim::wave_lev_resident_per_cu(); // never more than fit: the grid is persistent
+        if (resident >= 1 && resident < c->lev_waves_per_cu) c->lev_waves_per_cu = resident;
+    }
     if (const char *env = getenv("STRSIM_LEV_WAVES_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 256) c->lev_waves_per_cu = v;

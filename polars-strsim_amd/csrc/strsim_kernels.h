@@ -21,6 +21,10 @@ constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
 #define STRSIM_LEV_BYTES_ROWS 64 // pattern rows per lane of an ASCII batch of k_wave_pairs<levenshtein>: 64 (two mask words) or 32
 #endif
 constexpr int LEV_BYTES_ROWS = STRSIM_LEV_BYTES_ROWS;
+#ifndef STRSIM_LEV_POOL
+#define STRSIM_LEV_POOL 256 // rows ranked together before they are dealt into batches (a multiple of 64, at most 256)
+#endif
+constexpr int LEV_POOL = STRSIM_LEV_POOL;
 constexpr int TXT_PAD = 48;
 constexpr int ARENA0_BYTES = 8192;
 constexpr int ARENA1_BYTES = 12288;
@@ -81,6 +85,7 @@ hipError_t launch_slow_all_only(const LaunchArgs &a, double *const outs[5], unsi
 bool lane_kernel_reports(int measure, const LaunchArgs &a);
 // launches the first kernel of such a call takes: 1, or 2 when a literal takes k_lane_lit (+ k_publish_lit behind it)
 int lane_kernel_launches(int measure, const LaunchArgs &a);
+int wave_lev_resident_per_cu();
 
 // All five measures in one go (a.out unused): outs[] indexed by measure id; mask_backup = ceil(n/64) words of scratch.
 hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);

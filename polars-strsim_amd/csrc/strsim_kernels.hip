@@ -1613,6 +1613,9 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
 #else
 #define STRSIM_WAVE_OCCUPANCY
 #endif
+#ifndef STRSIM_LEV_PLENTY_Q
+#define STRSIM_LEV_PLENTY_Q 2 // quarters of (waves x pool chunks) left on the list below which chunks are dealt one by one
+#endif
 template <int MEASURE>
 __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
                                                    uint64_t rowsA, const uint32_t *__restrict__ offB,
@@ -1650,7 +1653,13 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
 #define STRSIM_WAVE_TAB_WORDS (2 * LUT_ENTRIES * 64)
 #endif
     __shared__ __attribute__((aligned(4096))) uint32_t s_tab[LEV ? STRSIM_WAVE_TAB_WORDS : 1];
-    __shared__ uint8_t s_order[64], s_blk[64];
+    // Levenshtein: the pooled rows in the order of their ranking -- bits 0..5 row of its chunk, 6..10 slot of the chunk in
+    // s_pool_chunk, 11..15 the lanes an ASCII job of the row takes (half the 32-row blocks of its shorter side, rounded up; 0: not
+    // a candidate for the block kernel) -- and the ranks still to do.  (The kernel's LDS is counted in 1 280-byte granules:
+    // with 7 968 bytes the CU held 18 waves, not 20.)
+    __shared__ uint32_t s_pool_chunk[LEV ? 32 : 1];
+    __shared__ uint16_t s_pool[LEV ? LEV_POOL : 1];
+    __shared__ unsigned long long s_todo[LEV ? LEV_POOL / 64 : 1];
     const uint32_t lane = lane_id();
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
@@ -1711,70 +1720,125 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
     const uint32_t C = status->list_count[MEASURE], R = status->list_rows[MEASURE];
     const uint32_t budget = (R >> 6) > 8192u ? (R >> 6) : 8192u;
     const uint32_t grab = C / budget >= 64u ? 64u : (C / budget ? C / budget : 1u);
+    // Levenshtein pools the rows of up to LEV_POOL / 64 chunks: it takes that many entries at a time while plenty of work is
+    // left behind the grab -- it looks at the counter first --; the tail of the list is dealt chunk by chunk, so that the waves
+    // still finish together (a pool of four dense chunks of cfg5 is a quarter of a wave's whole share).
+    const uint32_t big = (LEV && grab < (uint32_t)(LEV_POOL / 64)) ? (uint32_t)(LEV_POOL / 64) : grab;
+    const uint32_t plenty = gridDim.x * big * (uint32_t)STRSIM_LEV_PLENTY_Q / 4u;
+    const uint32_t g0 = C > gridDim.x * big + plenty ? big : grab; // the static first grab
     for (uint32_t round = 0;; ++round) {
-        uint32_t got = blockIdx.x * grab;
+        uint32_t got = blockIdx.x * g0, take = g0;
         if (round != 0u) {
-            if (lane == 0u) got = atomicAdd(&status->next_entry[MEASURE], grab);
-            got = uniform(got) + gridDim.x * grab;
+            if (lane == 0u) {
+                take = grab;
+                if (big != grab) {
+                    const uint32_t at = __hip_atomic_load(&status->next_entry[MEASURE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gridDim.x * g0;
+                    if (C > at && C - at > plenty) take = big;
+                }
+                got = atomicAdd(&status->next_entry[MEASURE], take);
+            }
+            take = uniform(take);
+            got = uniform(got) + gridDim.x * g0;
         }
         if (got >= C) break;
-        const bool have = lane < grab && got + lane < C;
+        const bool have = lane < take && got + lane < C;
         const uint32_t entry = have ? worklist[got + lane] : 0u;
         const unsigned long long mword = have ? slowmask[entry] : 0ull;
         unsigned long long pending = __ballot(mword != 0ull);
         while (pending != 0ull) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(pending);
-            pending &= pending - 1ull;
-            const uint64_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)entry, (int)src);
-            const unsigned long long mask =
-                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
-            // Levenshtein runs several rows at a time for max(steps) of them: the chunk's rows are ranked in
-            // descending order of their step count (longer length + blocks of the shorter - 1) so that the rows of
-            // a batch are alike, and each batch is filled first-fit from that order (rows whose lane run does not
-            // fit any more are skipped and start or join a later batch).
-            const uint32_t nvisit = (uint32_t)__popcll(mask);
-            unsigned long long todo = mask; // bit = row of the chunk; Levenshtein: bit = position in the ranking
-            if (MEASURE == LEVENSHTEIN) {
-                uint32_t key = 0u, nblk = 0u;
-                const bool mine = (mask >> lane) & 1ull;
-                if (mine) {
-                    const uint64_t rw = chunk * 64u + lane;
-                    const uint64_t ra = bcastA ? 0 : rw, rb = bcastB ? 0 : rw;
-                    const uint32_t x = offA[ra + 1] - offA[ra], y = offB[rb + 1] - offB[rb];
-                    const uint32_t mx = x > y ? x : y, mn = x < y ? x : y;
-                    if (mn != 0u && mx <= (uint32_t)WAVE_CAP) {
-                        nblk = (mn + 31u) >> 5;
-                        key = mx + nblk;
+            auto next_chunk = [&](uint64_t &chunk, unsigned long long &mask) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+                pending &= pending - 1ull;
+                chunk = (uint32_t)__builtin_amdgcn_readlane((int)entry, (int)src);
+                mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), (int)src) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, (int)src);
+            };
+            uint64_t chunk1 = 0;            // the other measures: one chunk at a time, its rows in row order
+            unsigned long long mask1 = 0ull;
+            uint32_t npool = 0u;
+            if constexpr (LEV) {
+                // Levenshtein runs several rows at a time for max(steps) of them, so the rows of a batch should be alike: the
+                // rows of up to LEV_POOL / 64 chunks are pooled and ranked in descending order of their step count (longer
+                // length + blocks of the shorter - 1), and each batch is filled first-fit from that order (rows whose lane
+                // run does not fit any more are skipped and start or join a later batch).  One chunk's 64 rows left a tenth
+                // of the lane-steps to rows shorter than their batch; 256 rows leave 4 % (cfg5).
+                __syncthreads();
+                uint32_t nslot = 0u;
+                while (pending != 0ull && npool + 64u <= (uint32_t)LEV_POOL && nslot < 32u) {
+                    uint64_t chunk;
+                    unsigned long long mask;
+                    next_chunk(chunk, mask);
+                    if (lane == 0u) s_pool_chunk[nslot] = (uint32_t)chunk;
+                    if ((mask >> lane) & 1ull)
+                        s_pool[npool + (uint32_t)__popcll(mask & lanemask_lt(lane))] = (uint16_t)(lane | (nslot << 6));
+                    npool += (uint32_t)__popcll(mask);
+                    ++nslot;
+                }
+                __syncthreads();
+                constexpr int PG = LEV_POOL / 64;
+                uint32_t key[PG], code[PG], rank[PG];
+#pragma unroll
+                for (int k = 0; k < PG; ++k) {
+                    key[k] = 0u; code[k] = 0u; rank[k] = 0u;
+                    const uint32_t pidx = lane + 64u * (uint32_t)k;
+                    if (pidx < npool) {
+                        code[k] = s_pool[pidx];
+                        const uint64_t rw = (uint64_t)s_pool_chunk[code[k] >> 6] * 64u + (code[k] & 63u);
+                        const uint64_t ra = bcastA ? 0 : rw, rb = bcastB ? 0 : rw;
+                        const uint32_t x = offA[ra + 1] - offA[ra], y = offB[rb + 1] - offB[rb];
+                        const uint32_t mx = x > y ? x : y, mn = x < y ? x : y;
+                        if (mn != 0u && mx <= (uint32_t)WAVE_CAP) {
+                            const uint32_t nblk = (mn + 31u) >> 5;
+                            key[k] = mx + nblk;
+                            code[k] |= ((nblk + 1u) >> 1) << 11;
+                        }
                     }
                 }
-                uint32_t rank = 0u;
-                for (unsigned long long mm = mask; mm != 0ull; mm &= mm - 1ull) {
-                    const uint32_t jl = (uint32_t)__builtin_ctzll(mm);
-                    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)jl);
-                    rank += (kj > key || (kj == key && jl < lane)) ? 1u : 0u;
+                // rank = rows of the pool in front of this one: a larger key, or the same key and a smaller pool index
+#pragma unroll
+                for (int k2 = 0; k2 < PG; ++k2) {
+                    const uint32_t cnt = npool > 64u * (uint32_t)k2 ? (npool - 64u * (uint32_t)k2 < 64u ? npool - 64u * (uint32_t)k2 : 64u) : 0u;
+                    for (uint32_t jl = 0; jl < cnt; ++jl) {
+                        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key[k2], (int)jl);
+#pragma unroll
+                        for (int k = 0; k < PG; ++k)
+                            rank[k] += (k2 < k ? kj >= key[k] : (k2 > k ? kj > key[k] : (kj > key[k] || (kj == key[k] && jl < lane)))) ? 1u : 0u;
+                    }
+                }
+                __syncthreads(); // every lane has read its rows: the pool is rewritten in ranking order
+#pragma unroll
+                for (int k = 0; k < PG; ++k)
+                    if (lane + 64u * (uint32_t)k < npool) s_pool[rank[k]] = (uint16_t)code[k];
+                if (lane < (uint32_t)PG) {
+                    const uint32_t cnt = npool > 64u * lane ? npool - 64u * lane : 0u;
+                    s_todo[lane] = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull); // bit = position in the ranking
                 }
                 __syncthreads();
-                if (mine) {
-                    s_order[rank] = (uint8_t)lane;
-                    s_blk[rank] = (uint8_t)nblk; // 0: not a candidate for the block kernel (empty side / too long)
-                }
-                __syncthreads();
-                todo = nvisit == 64u ? ~0ull : ((1ull << nvisit) - 1ull);
+            } else {
+                next_chunk(chunk1, mask1);
             }
-            while (todo != 0ull) {
-              for (unsigned long long scan = todo; scan != 0ull; scan &= scan - 1ull) {
-                const uint32_t vi = (uint32_t)__builtin_ctzll(scan);
-                uint32_t bitpos = vi;
-                if (MEASURE == LEVENSHTEIN) {
-                    const uint32_t need = uniform((uint32_t)s_blk[vi]); // upper bound: blocks of the shorter BYTE length
-                    // no room in this pass (a BYTES job takes a lane per LEV_BYTES_ROWS rows, a SYMBOLS job one per 32)
-                    const uint32_t need0 = (need * 32u + (uint32_t)LEV_BYTES_ROWS - 1u) / (uint32_t)LEV_BYTES_ROWS;
-                    if (bq0.lanes + need0 > 64u || bq1.lanes + need > 64u) continue;
-                    bitpos = uniform((uint32_t)s_order[vi]);
+            const uint32_t nwords = LEV ? (npool + 63u) >> 6 : 1u;
+            for (;;) {
+              bool left = false;
+#pragma unroll 1
+              for (uint32_t wsel = 0; wsel < nwords; ++wsel) {
+              unsigned long long cur = mask1; // rows (other measures) / ranks (Levenshtein) of this word still to do
+              if constexpr (LEV) {
+                  const unsigned long long tw = s_todo[wsel];
+                  cur = ((unsigned long long)uniform((uint32_t)(tw >> 32)) << 32) | uniform((uint32_t)tw);
+              }
+              for (unsigned long long scan = cur; scan != 0ull; scan &= scan - 1ull) {
+                const uint32_t vb = (uint32_t)__builtin_ctzll(scan);
+                uint64_t row = chunk1 * 64u + vb;
+                if constexpr (LEV) {
+                    const uint32_t code = uniform((uint32_t)s_pool[64u * wsel + vb]);
+                    // no room in this pass: an ASCII job takes a lane per 64 rows of its shorter side, any other one per 32 (for
+                    // those the code holds an upper bound)
+                    const uint32_t need0 = LEV_BYTES_ROWS == 64 ? code >> 11 : 2u * (code >> 11);
+                    if (bq0.lanes + need0 > 64u || bq1.lanes + 2u * (code >> 11) > 64u) continue;
+                    row = (uint64_t)uniform(s_pool_chunk[(code >> 6) & 31u]) * 64u + (code & 63u);
                 }
-                todo &= ~(1ull << vi);
-                const uint64_t row = chunk * 64u + bitpos;
+                cur &= ~(1ull << vb);
                 const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
                 const uint32_t a0 = uniform(offA[ra]), a1 = uniform(offA[ra + 1]);
                 const uint32_t b0 = uniform(offB[rb]), b1 = uniform(offB[rb + 1]);
@@ -1872,10 +1936,18 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
                 const double r = wave_row<MEASURE>(valA, a0, la8, totalA, valB, b0, lb8, totalB, sA, sB, aux, WAVE_CAP, LEV ? WAVE_CAP + 64 : AUXW);
                 if (lane == 0u) out[row] = r;
               }
-              if (todo != 0ull) { // rows are left that did not fit: run what has been collected
-                  flush_bytes();
-                  flush_symbols();
+              if constexpr (LEV) {
+                  if (lane == 0u) s_todo[wsel] = cur;
+              } else {
+                  mask1 = cur;
               }
+              left = left || cur != 0ull;
+              }
+              if (!left) break;
+              // rows are left that did not fit: run what has been collected
+              __syncthreads();
+              flush_bytes();
+              flush_symbols();
             }
         }
     }
@@ -2181,6 +2253,18 @@ hipError_t launch_pairs_all(const LaunchArgs &a, double *const outs[5], unsigned
     hipError_t e = launch_lane_all_only(a, outs);
     if (e != hipSuccess) return e;
     return launch_slow_all_only(a, outs, mask_backup);
+}
+
+// waves of k_wave_pairs<levenshtein> a CU holds at once (its grid is persistent: a wave that is not resident would start on
+// its static share of the work list only when another one leaves); 0 if the runtime cannot tell
+int wave_lev_resident_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wave_pairs<LEVENSHTEIN>, 64, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
 }
 
 int lane_kernel_launches(int measure, const LaunchArgs &a)

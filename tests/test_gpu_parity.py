@@ -162,6 +162,45 @@ def test_long_ascii_levenshtein_many_batches_per_wave(S, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("waves", ["1", "20"])
+def test_long_levenshtein_rows_pooled_across_chunks(S, monkeypatch, waves):
+    """k_wave_pairs<levenshtein> ranks the rows of several 64-row chunks together before it deals them into batches: long rows
+    that are sparse (a few per chunk, so a pool spans many chunks), dense stretches (a pool is four full chunks), and every kind
+    of row in the same pool -- ASCII with 64-row blocks, long Cyrillic / CJK (32-row blocks of symbols), an empty side, strings
+    past 1 024 bytes (left to the long-string pass) -- against the oracle."""
+    import random
+    monkeypatch.setenv("STRSIM_LEV_WAVES_PER_CU", waves)
+    rng = random.Random(4242)
+    def text(alpha, lo, hi):
+        return "".join(rng.choice(alpha) for _ in range(rng.randint(lo, hi)))
+    A, B = [], []
+    for i in range(30000):
+        dense = 9000 <= i < 11000
+        r = rng.random()
+        if dense or r < 0.03:
+            kind = rng.random()
+            if kind < 0.70:
+                A.append(text("abcdefghijklmnopqrstuvwxyz", 1, 1024)); B.append(text("abcdefghijklmnopqrstuvwxyz", 129, 1024))
+            elif kind < 0.80:
+                A.append(text("abcXYZ 019.,", 129, 700)); B.append(text("abcXYZ 019.,", 1, 700))
+            elif kind < 0.88:
+                A.append(text("абвгдежзийклмн", 70, 400)); B.append(text("абвгдежзийклмн", 70, 400))
+            elif kind < 0.92:
+                A.append(text("日本語の文字列漢字", 50, 300)); B.append(text("abc日本", 50, 300))
+            elif kind < 0.96:
+                A.append(""); B.append(text("abc", 129, 900))
+            else:
+                A.append(text("ab", 1025, 1500)); B.append(text("ab", 200, 1100))
+        else:
+            A.append(text("abcdefgh", 0, 30)); B.append(text("abcdefgh", 0, 30))
+    c = S.Context(0)
+    try:
+        got = gpu(S, c, "levenshtein", A, B)
+        assert_bit_exact(got, O.batch_strings("levenshtein", A, B, 16), A, B, "levenshtein")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
