@@ -1073,9 +1073,11 @@ __device__ __forceinline__ void wave_lev_blocks64(const BlockJob *jobs, uint32_t
 #else
         c.llo = c.lhi = al; c.mlo = c.mhi = am; // (host pass of hipcc: never run)
 #endif
-        if (NP > 5) {
-            c.mlo &= lut_high_planes<NP>(Plo, w, q);
-            c.mhi &= lut_high_planes<NP>(Phi, w, q);
+#pragma unroll
+        for (int k = 5; k < NP; ++k) { // planes 5.. on top of M: m & ~(P_k ^ bit k of the column's byte)
+            const uint32_t fill = bit_fill(w, 8 * q + k);
+            c.mlo = bitop3<0x90>(c.mlo, Plo[k < NP ? k : 0], fill);
+            c.mhi = bitop3<0x90>(c.mhi, Phi[k < NP ? k : 0], fill);
         }
         return c;
     };
