@@ -290,6 +290,11 @@ constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
 #endif
 constexpr int WIDE_SPAN = STRSIM_WIDE_SPAN;  // mask words (64-row chunks) per span of k_lane_wide
 constexpr int WIDE_ROWS = WIDE_SPAN * 64;    // 4096 rows
+#ifndef STRSIM_WIDE_LIST
+#define STRSIM_WIDE_LIST 6144 // rows on k_lane_wide's sorted list (at least WIDE_ROWS): 12 KB, what the LDS of three workgroups per CU has left
+#endif
+constexpr int WIDE_LIST = STRSIM_WIDE_LIST;
+static_assert(WIDE_LIST >= WIDE_ROWS && WIDE_BLOCK * 64 <= 65536, "one span always fits the list; list entries are 16-bit row indices of a super");
 constexpr int U8_SPAN = 32;                  // ... of k_lane_utf8 (its symbol columns take the LDS: a larger span costs a workgroup per CU)
 constexpr int U8_ROWS = U8_SPAN * 64;        // 2048 rows
 constexpr int WIDE_MAXW = 4;
@@ -405,15 +410,21 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                                                           double *__restrict__ out, uint64_t n,
                                                           unsigned long long *__restrict__ slowmask, uint32_t sps)
 {
-    __shared__ unsigned long long s_mask[WIDE_SPAN];
-    __shared__ uint32_t s_cnt[24];              // rows per key = width class (3: <= 64, <= 96, <= 128 bytes) x column-count bucket (8)
-    __shared__ uint32_t s_next;                 // next round to hand out
-    __shared__ uint16_t s_list[WIDE_ROWS];      // candidate rows (index within the span), sorted by key
+    // A workgroup takes a SUPER-span of up to WIDE_BLOCK mask words (16 384 rows: sps spans of WIDE_SPAN words, one word per
+    // thread), collects the flagged rows it can run into an LDS list sorted by (width class, columns to run), and runs the list
+    // 64 rows at a time.  The longer the list, the more alike the rows of a round: cfg3's rounds ran 74 % of their
+    // lane-columns on a row that needed them with lists of one span (4 096 rows, 24 keys of 8 / 16 columns), 90 % with the whole
+    // super and keys of 4 columns.  A super whose candidates do not fit the list (WIDE_LIST entries) is done span by span.
+    constexpr int NKEY = 96;                    // 3 width classes (masks of 2 / 3 / 4 words) x 32 column counts (4 columns each)
+    __shared__ unsigned long long s_mask[WIDE_BLOCK];
+    __shared__ uint32_t s_cnt[NKEY];            // rows per key, then the key's next free list position
+    __shared__ uint32_t s_next, s_total;        // next round to hand out; rows on the list
+    __shared__ uint16_t s_list[WIDE_LIST];      // candidate rows (index within the super), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
     __shared__ uint32_t s_fa[WIDE_WAVES][WIDE_MAXW + 1][64];
 
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
-    constexpr int RPT = WIDE_ROWS / WIDE_BLOCK; // rows per thread in the collection phase
+    constexpr int RPS = WIDE_ROWS / WIDE_BLOCK; // rows per thread and span in the collection phase
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     __builtin_amdgcn_s_setprio(1);
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
@@ -421,63 +432,82 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     const uint64_t nchunks = (n + 63u) >> 6;
     const uint64_t nspans = (nchunks + WIDE_SPAN - 1) / WIDE_SPAN;
 
-    // Super-spans of WIDE_BLOCK mask words (one per thread, coalesced): a workgroup-wide OR decides whether
-    // any of its WIDE_BLOCK / WIDE_SPAN spans needs work at all -- the common all-clear case costs one barrier.
     // sps spans per super (1 .. WIDE_BLOCK / WIDE_SPAN, chosen by the launcher so that a mid-size frame still makes
-    // enough workgroups to fill the chip)
+    // enough workgroups to fill the chip); the common all-clear super costs one coalesced read and one barrier
     const uint64_t nsuper = (nspans + sps - 1) / sps;
     const uint32_t super_words = sps * (uint32_t)WIDE_SPAN;
     for (uint64_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-      const uint64_t cw = sup * super_words + tid;
-      const unsigned long long myword = (tid < super_words && cw < nchunks) ? slowmask[cw] : 0ull;
+      const uint64_t cw0 = sup * super_words;
+      const unsigned long long myword = (tid < super_words && cw0 + tid < nchunks) ? slowmask[cw0 + tid] : 0ull;
       if (!__syncthreads_or(myword != 0ull)) continue;
-      for (uint64_t span = sup * sps; span < (sup + 1) * sps && span < nspans; ++span) {
-        const uint64_t c0 = span * WIDE_SPAN;
-        if (tid < (uint32_t)WIDE_SPAN) s_mask[tid] = (c0 + tid < nchunks) ? slowmask[c0 + tid] : 0ull;
-        if (tid < 24u) s_cnt[tid] = 0u;
-        if (tid == 24u) s_next = 0u;
+      s_mask[tid] = myword;
+      uint32_t gsz = sps; // spans per list: the whole super, or one at a time when that does not fit
+      for (uint32_t g0 = 0; g0 < sps;) {
+        if (tid < (uint32_t)NKEY) s_cnt[tid] = 0u;
+        if (tid == (uint32_t)NKEY) s_next = 0u;
         lds_barrier();
-        const bool any = __ballot(s_mask[lane & (WIDE_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
-        if (any) {
-            // ---- collect rows with 33..128-byte strings on the longer side and a non-empty shorter side; key them by
-            //      width class (W = 2 / 4) and by the number of DP columns they will run (the text length)
-            uint32_t key[RPT], rank[RPT];
+        // ---- key of a flagged row: 33..128-byte strings on the longer side and a non-empty shorter side; width class, then the
+        //      number of DP columns (the text length).  Both passes over the rows compute it (the second one finds the offsets in L2):
+        //      keeping 64 keys per thread between them cost more registers than the kernel has.
+        auto row_key = [&](uint32_t i) -> uint32_t { // 0x7F: not a candidate
+            if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0x7Fu;
+            const uint64_t row = cw0 * 64u + i;
+            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+            const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
+            const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
+            if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0x7Fu;
+            const uint32_t steps = SYMMETRIC ? mn : la8;
+            const uint32_t cls = mx > 96u ? 2u : (mx > 64u ? 1u : 0u); // masks of 4 / 3 / 2 words
+            return cls * 32u + ((steps - 1u) >> 2);
+        };
+#pragma unroll 1
+        for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const uint32_t i = k * WIDE_BLOCK + tid;
-                key[k] = 0xFFFFFFFFu;
-                if ((s_mask[i >> 6] >> (i & 63u)) & 1ull) {
-                    const uint64_t row = c0 * 64u + i;
-                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-                    const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
-                    const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
-                    if (mx > 32u && mx <= 128u && mn >= 1u) {
-                        const uint32_t steps = SYMMETRIC ? mn : la8;
-                        const uint32_t cls = mx > 96u ? 2u : (mx > 64u ? 1u : 0u); // masks of 4 / 3 / 2 words
-                        key[k] = cls * 8u + ((steps - 1u) >> (cls ? 4 : 3));
-                        rank[k] = atomicAdd(&s_cnt[key[k]], 1u);
-                    }
-                }
+            for (int kk = 0; kk < RPS; ++kk) {
+                const uint32_t key = row_key((sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid);
+                if (key != 0x7Fu) atomicAdd(&s_cnt[key], 1u);
             }
+        }
+        lds_barrier();
+        // ---- list positions: exclusive prefix sum of the 96 counters (wave 0, two keys per lane)
+        if (wv == 0u) {
+            const uint32_t c0k = lane < (uint32_t)(NKEY / 2) ? s_cnt[2u * lane] : 0u;
+            const uint32_t c1k = lane < (uint32_t)(NKEY / 2) ? s_cnt[2u * lane + 1u] : 0u;
+            uint32_t inc = c0k + c1k;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)inc, d);
+                if (lane >= (uint32_t)d) inc += up;
+            }
+            if (lane < (uint32_t)(NKEY / 2)) {
+                s_cnt[2u * lane] = inc - c0k - c1k;
+                s_cnt[2u * lane + 1u] = inc - c1k;
+            }
+            if (lane == 63u) s_total = inc;
+        }
+        lds_barrier();
+        const uint32_t total = s_total;
+        if (total > (uint32_t)WIDE_LIST) { // (only with gsz > 1: one span holds WIDE_ROWS <= WIDE_LIST rows)
+            // as many spans per list as fit at this density, a power of two (checked again on the next trip)
+            const uint32_t fit = gsz * (uint32_t)WIDE_LIST / total;
+            gsz = fit >= 2u ? 2u : 1u;
             lds_barrier();
-            uint32_t total = 0;
-            {
-                uint32_t c[24];
+            continue;
+        }
+        if (total != 0u) {
+#pragma unroll 1
+            for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
 #pragma unroll
-                for (int q = 0; q < 24; ++q) { c[q] = s_cnt[q]; total += c[q]; }
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    if (key[k] == 0xFFFFFFFFu) continue;
-                    uint32_t base = 0;
-#pragma unroll
-                    for (int q = 0; q < 23; ++q) base += ((uint32_t)q < key[k]) ? c[q] : 0u;
-                    s_list[base + rank[k]] = (uint16_t)(k * WIDE_BLOCK + tid);
+                for (int kk = 0; kk < RPS; ++kk) {
+                    const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
+                    const uint32_t key = row_key(i);
+                    if (key != 0x7Fu) s_list[atomicAdd(&s_cnt[key], 1u)] = (uint16_t)i;
                 }
             }
             lds_barrier();
             // ---- rounds of 64 rows of similar width and length, longest first; a wave takes the next one when it is done
             //      (a four-word round costs four times a two-word one: dealing them out in turn leaves waves idle at the
-            //      barrier behind the span)
+            //      barrier behind the list)
             const uint32_t nrounds = (total + 63u) >> 6;
             for (;;) {
                 uint32_t rr = 0u;
@@ -488,7 +518,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 const uint32_t li = r * 64u + lane;
                 const bool has = li < total;
                 const uint32_t i = has ? s_list[li] : 0u;
-                const uint64_t row = c0 * 64u + i;
+                const uint64_t row = cw0 * 64u + i;
                 uint32_t a0 = 0, la = 0, b0 = 0, lb = 0;
                 if (has) {
                     const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
@@ -514,11 +544,12 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
             }
-            lds_barrier();
-            if (tid < (uint32_t)WIDE_SPAN && c0 + tid < nchunks) slowmask[c0 + tid] = s_mask[tid];
         }
         lds_barrier();
+        g0 += gsz;
       }
+      if (tid < super_words && cw0 + tid < nchunks) slowmask[cw0 + tid] = s_mask[tid];
+      lds_barrier();
     }
 }
 

@@ -201,6 +201,35 @@ def test_long_levenshtein_rows_pooled_across_chunks(S, monkeypatch, waves):
         c.close()
 
 
+@pytest.mark.parametrize("density", [0.3, 0.55, 1.0])
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_wide_rows_at_every_list_density(S, ctx, measure, density):
+    """k_lane_wide sorts the 33..128-byte rows of a 16 384-row super-span into one list when they fit it (6 144 rows), of half
+    a super when those do, else span by span: frames with 30 %, 55 % and 100 % of such rows take the three paths."""
+    import random
+    rng = random.Random(int(density * 100))
+    A, B = [], []
+    for _ in range(40000):
+        if rng.random() < density:
+            la, lb = rng.randint(1, 128), rng.randint(33, 128)
+            if rng.random() < 0.5:
+                la, lb = lb, la
+        else:
+            la, lb = rng.randint(0, 32), rng.randint(0, 32)
+        a = "".join(rng.choice("abcdefghij") for _ in range(la))
+        # half of the pairs are edited copies (matches, transpositions, common prefixes for Jaro-Winkler)
+        if rng.random() < 0.5 and la and lb:
+            b = list(a[:lb]) + [rng.choice("abcdefghij") for _ in range(max(0, lb - la))]
+            for _ in range(rng.randint(0, 4)):
+                b[rng.randrange(len(b))] = rng.choice("abcxyz")
+            b = "".join(b)
+        else:
+            b = "".join(rng.choice("abcdefghij") for _ in range(lb))
+        A.append(a); B.append(b)
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 16), A, B, measure)
+
+
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
