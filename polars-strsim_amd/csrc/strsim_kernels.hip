@@ -447,8 +447,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         if (tid == (uint32_t)NKEY) s_next = 0u;
         lds_barrier();
         // ---- key of a flagged row: 33..128-byte strings on the longer side and a non-empty shorter side; width class, then the
-        //      number of DP columns (the text length).  Both passes over the rows compute it (the second one finds the offsets in L2):
-        //      keeping 64 keys per thread between them cost more registers than the kernel has.
+        //      number of DP columns (the text length).  The keys wait for the second pass in the text columns' LDS, idle until
+        //      the rounds start (64 keys per thread in registers cost more than the kernel has: 1.6 KB of scratch per lane).
+        uint8_t *const s_key = reinterpret_cast<uint8_t *>(&s_txt[0][0][0]);
+        static_assert(sizeof(s_txt) >= (size_t)WIDE_BLOCK * 64, "a key byte per row of a super");
         auto row_key = [&](uint32_t i) -> uint32_t { // 0x7F: not a candidate
             if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0x7Fu;
             const uint64_t row = cw0 * 64u + i;
@@ -464,7 +466,9 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
 #pragma unroll
             for (int kk = 0; kk < RPS; ++kk) {
-                const uint32_t key = row_key((sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid);
+                const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
+                const uint32_t key = row_key(i);
+                s_key[i] = (uint8_t)key;
                 if (key != 0x7Fu) atomicAdd(&s_cnt[key], 1u);
             }
         }
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
 #pragma unroll
                 for (int kk = 0; kk < RPS; ++kk) {
                     const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
-                    const uint32_t key = row_key(i);
+                    const uint32_t key = s_key[i];
                     if (key != 0x7Fu) s_list[atomicAdd(&s_cnt[key], 1u)] = (uint16_t)i;
                 }
             }
