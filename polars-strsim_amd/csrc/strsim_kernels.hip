@@ -1076,9 +1076,13 @@ __device__ __forceinline__ void wave_lev_blocks64(const BlockJob *jobs, uint32_t
     uint64_t Pv = valid, Mv = ~valid;
     const uint32_t first = blk == 0u ? 1u : 0u;
     const uint32_t pubw = blk + 1u == B ? 0u : 1u;
-    // Hand-off: the +1 and the -1 leaving a block's bottom row travel in two registers (one DPP move each, the +1 one
-    // fused with the OR of `first`), so neither side packs or unpacks anything.
+    // Hand-off: the +1 and the -1 leaving a block's bottom row travel in two registers, so neither side packs or unpacks
+    // anything.  The +1 is not even extracted: the neighbour fetches the block's whole top Ph word (one v_or_b32_dpp that also
+    // sets the top bit for the first block of a job -- whatever the last block of the job in front of it left there) and
+    // shifts its top bit into its own Ph with the v_alignbit that shifts Ph anyway.  The -1 is needed at bit 0 as well (it joins
+    // the match mask), so it is published as a bit.
     uint32_t houtP = 0u, houtN = 0u;
+    const uint32_t first_top = first << 31;
     typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const uint32_t txt0 = 4u * (uint32_t)jobs[jdx].txt + TXT_PAD; // this job's column 0 in the arena (uniform base + 32-bit offset)
     const uint32_t ncol = mine ? n : 0u;
@@ -1119,7 +1123,7 @@ __device__ __forceinline__ void wave_lev_blocks64(const BlockJob *jobs, uint32_t
     // RAMP: the first steps, while blocks are still starting (block k runs columns from step k on); after step 16 every
     // block has started and "has a column left" is one compare against the uniform step.
     auto step = [&](const Col &c, auto ramp) {
-        uint32_t hinP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtP, 0x138 /* wave_shr:1 */, 0xF, 0xF, true) | first;
+        uint32_t hinP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtP, 0x138 /* wave_shr:1 */, 0xF, 0xF, true) | first_top;
         asm volatile("" : "+v"(hinP)); // keeps the OR next to the move (one v_or_b32_dpp) instead of behind the shift that uses it
         const uint32_t hinN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtN, 0x138, 0xF, 0xF, true);
         const bool on = decltype(ramp)::value ? (tt - blk) < ncol : tt < end;
@@ -1127,13 +1131,15 @@ __device__ __forceinline__ void wave_lev_blocks64(const BlockJob *jobs, uint32_t
             const uint32_t Pvl = (uint32_t)Pv, Pvh = (uint32_t)(Pv >> 32), Mvl = (uint32_t)Mv, Mvh = (uint32_t)(Mv >> 32);
             const uint32_t Xvl = bitop3<0xEA>(c.llo, c.mlo, Mvl), Xvh = bitop3<0xEA>(c.lhi, c.mhi, Mvh); // Eq0 | Mv
             const uint32_t Eql = bitop3<0xEA>(c.llo, c.mlo, hinN), Eqh = c.lhi & c.mhi;                    // Eq0 | hinN
-            const uint64_t sum = (((uint64_t)(Eqh & Pvh) << 32) | (Eql & Pvl)) + Pv;
+            uint64_t masked = ((uint64_t)(Eqh & Pvh) << 32) | (Eql & Pvl);
+            asm volatile("" : "+v"(masked)); // one 64-bit add on the register pair (left alone the compiler adds the halves apart: + 1)
+            const uint64_t sum = masked + Pv;
             const uint32_t Xhl = bitop3<0xBE>((uint32_t)sum, Pvl, Eql), Xhh = bitop3<0xBE>((uint32_t)(sum >> 32), Pvh, Eqh);
             const uint32_t Phl = bitop3<0xF1>(Mvl, Xhl, Pvl), Phh = bitop3<0xF1>(Mvh, Xhh, Pvh);
             const uint32_t Mhl = Pvl & Xhl, Mhh = Pvh & Xhh;
-            houtP = bfe_u32(Phh, 31u, pubw);
+            houtP = Phh;
             houtN = bfe_u32(Mhh, 31u, pubw);
-            const uint32_t PhSl = (Phl << 1) | hinP, PhSh = (uint32_t)__builtin_amdgcn_alignbit(Phh, Phl, 31);
+            const uint32_t PhSl = (uint32_t)__builtin_amdgcn_alignbit(Phl, hinP, 31), PhSh = (uint32_t)__builtin_amdgcn_alignbit(Phh, Phl, 31);
             const uint32_t MhSl = (Mhl << 1) | hinN, MhSh = (uint32_t)__builtin_amdgcn_alignbit(Mhh, Mhl, 31);
             Pv = ((uint64_t)bitop3<0xF1>(MhSh, Xvh, PhSh) << 32) | bitop3<0xF1>(MhSl, Xvl, PhSl);
             Mv = ((uint64_t)(PhSh & Xvh) << 32) | (PhSl & Xvl);
