@@ -926,13 +926,13 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
     }
     const uint32_t valid = blk == 0u ? ~low_ones(s) : 0xFFFFFFFFu;
     uint32_t Pv = valid, Mv = ~valid;
-    // Hand-off word of a block: bit 0 = +1, bit 1 = -1 leaving its bottom row.  The LAST block of a job publishes 0
-    // (nobody below it), so the first block of the next job -- like lane 0, which the shift fills with 0 -- reads 0
-    // and adds its own constant +1 (the row above block 0 grows by one per column) through `first`.
-    const uint32_t first = blk == 0u ? 1u : 0u;
-    const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published +1 bit
-    const uint32_t pubn = blk + 1u == B ? 0u : 2u;  // mask of the published -1 bit
-    uint32_t hout = 0u;
+    // Hand-off of a block's bottom row to the block above it in the job (the next lane): the -1 as a bit (it joins the match
+    // mask at bit 0), the +1 as the block's whole Ph word -- the neighbour takes its top bit with the v_alignbit that shifts its
+    // own Ph.  The first block of a job (and lane 0, which the DPP shift fills with 0) ORs the top bit in: the row above block 0
+    // grows by one per column, whatever the last block of the job in front left in its word.
+    const uint32_t first_top = blk == 0u ? 0x80000000u : 0u;
+    const uint32_t pubw = blk + 1u == B ? 0u : 1u;  // field width of the published -1 bit (the LAST block of a job publishes 0)
+    uint32_t houtP = 0u, houtN = 0u;
     // Column j = t - blk of the text at step t.  A staged text has TXT_PAD units in front and behind (never used as
     // columns: a block is idle for blk <= 31 steps before its own columns), so a lane just walks on: four columns
     // per four steps, fetched two trips ahead with one unaligned load; once past its text (the batch runs for the
@@ -950,16 +950,18 @@ __device__ __forceinline__ void wave_lev_blocks(const BlockJob *jobs, uint32_t n
         else return *reinterpret_cast<const u32_unaligned *>(col0 + at);
     };
     auto step = [&](uint32_t Eq0) {
-        const uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+        uint32_t hinP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtP, 0x138 /* wave_shr:1 */, 0xF, 0xF, true) | first_top;
+        asm volatile("" : "+v"(hinP)); // one v_or_b32_dpp (the compiler would move the OR behind the shift that uses it)
+        const uint32_t hinN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)houtN, 0x138, 0xF, 0xF, true);
         if ((uint32_t)j < ncol) {
-            const uint32_t hinP = (hin & 1u) | first, hinN = hin >> 1;
             const uint32_t Xv = Eq0 | Mv;
             const uint32_t Eq = Eq0 | hinN;
             const uint32_t Xh = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq); // (sum ^ Pv) | Eq
             const uint32_t Ph = bitop3<0xF1>(Mv, Xh, Pv);             // Mv | ~(Xh | Pv)
             const uint32_t Mh = Pv & Xh;
-            hout = bfe_u32(Ph, 31u, pubw) | ((Mh >> 30) & pubn);
-            const uint32_t PhS = (Ph << 1) | hinP, MhS = (Mh << 1) | hinN;
+            houtP = Ph;
+            houtN = bfe_u32(Mh, 31u, pubw);
+            const uint32_t PhS = (uint32_t)__builtin_amdgcn_alignbit(Ph, hinP, 31), MhS = (Mh << 1) | hinN;
             Pv = bitop3<0xF1>(MhS, Xv, PhS);                          // MhS | ~(Xv | PhS)
             Mv = PhS & Xv;
         }
@@ -1299,23 +1301,45 @@ __device__ __forceinline__ uint32_t wave_lev_stripes(const uint32_t *pat, uint32
 
 // Copy the ASCII string p[0, len) into LDS bytes and/or just test it: returns true when every byte is < 0x80.
 // or6/and6 accumulate, wave-uniformly, whether bits 5 and 6 are set in any / in every byte (plane-count choice).
-__device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ p, uint32_t len, uint8_t *dst, uint32_t &or6,
-                                                 uint32_t &and6)
+// One pass over the two strings of a pair: are all their bytes ASCII, which of bits 5 / 6 vary over them (or6 / and6
+// accumulate over the jobs of a batch), and the text copied to its arena slot `dst` (4-aligned).
+__device__ __forceinline__ bool wave_ascii_stage(const uint8_t *__restrict__ pat, uint32_t mlen, const uint8_t *__restrict__ txt,
+                                                 uint32_t nlen, uint8_t *dst, uint32_t &or6, uint32_t &and6)
 {
+    // Four bytes per lane and trip (a string of 1 024 bytes: 4 trips; both strings in the same trip, so their loads are in
+    // flight together), OR / AND of the bytes kept per lane and reduced over the wave once at the end.  Until late in round 3:
+    // a pass per string, a byte per lane and five ballots per trip -- a tenth of k_wave_pairs<levenshtein>'s instructions on
+    // cfg5 and, one row after the other, a latency chain per row (207 -> 241 M pairs/s).  Staged, the last dword of a text
+    // reaches up to 3 bytes into its rear pad.
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const uint32_t lane = lane_id();
-    bool ascii = true;
-    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-        const uint32_t i = c0 + lane;
-        const bool in = i < len;
-        const uint32_t b = in ? p[i] : 0u;
-        if (__ballot(b >= 0x80u) != 0ull) ascii = false;
-        if (__ballot(in && (b & 0x20u)) != 0ull) or6 |= 0x20u;
-        if (__ballot(in && (b & 0x40u)) != 0ull) or6 |= 0x40u;
-        if (__ballot(in && !(b & 0x20u)) != 0ull) and6 &= ~0x20u;
-        if (__ballot(in && !(b & 0x40u)) != 0ull) and6 &= ~0x40u;
-        if (dst && in) dst[i] = (uint8_t)b;
+    uint32_t o = 0u, a = 0xFFFFFFFFu;
+    auto dword = [&](const uint8_t *p, uint32_t len, uint32_t i) {
+        const uint32_t rem = len - i;
+        uint32_t w;
+        if (rem >= 4u) {
+            w = *reinterpret_cast<const u32_unaligned *>(p + i);
+        } else { // the string's last one to three bytes, one by one: nothing is read behind a string
+            w = p[i];
+            if (rem > 1u) w |= (uint32_t)p[i + 1u] << 8;
+            if (rem > 2u) w |= (uint32_t)p[i + 2u] << 16;
+        }
+        const uint32_t keep = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8u * rem)) - 1u);
+        o |= w & keep;
+        a &= w | ~keep;
+        return w;
+    };
+    const uint32_t longest = mlen > nlen ? mlen : nlen;
+    for (uint32_t c0 = 0; c0 < longest; c0 += 256u) {
+        const uint32_t i = c0 + 4u * lane;
+        if (i < nlen) *reinterpret_cast<uint32_t *>(dst + i) = dword(txt, nlen, i);
+        if (i < mlen) (void)dword(pat, mlen, i);
     }
-    return ascii;
+    if (__ballot((o & 0x20202020u) != 0u) != 0ull) or6 |= 0x20u;
+    if (__ballot((o & 0x40404040u) != 0u) != 0ull) or6 |= 0x40u;
+    if (__ballot((a & 0x20202020u) != 0x20202020u) != 0ull) and6 &= ~0x20u;
+    if (__ballot((a & 0x40404040u) != 0x40404040u) != 0ull) and6 &= ~0x40u;
+    return __ballot((o & 0x80808080u) != 0u) == 0ull;
 }
 
 // In-place compaction of the flagged entries of s[0..len) to the front; returns how many.
@@ -1900,17 +1924,14 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
                     const bool a_short = la8 <= lb8;
                     const uint32_t ms = a_short ? la8 : lb8, nl = a_short ? lb8 : la8;
                     const uint32_t Bn = (ms + (uint32_t)LEV_BYTES_ROWS - 1u) / (uint32_t)LEV_BYTES_ROWS;
-                    uint32_t o6 = job_or6, n6 = job_and6;
-                    bool ascii = !long_bytes && wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
-                    if (ascii) {
+                    if (!long_bytes) {
+                        // (the first-fit test above left room for the lanes; the job list is flushed when it fills up: only the
+                        // text arena can be short here -- a row that then turns out not to be ASCII has flushed for nothing)
                         const uint32_t slot = (2u * TXT_PAD + nl + 3u) & ~3u;
-                        if (bq0.njobs == (uint32_t)LEV_JOBS || bq0.lanes + Bn > 64u || bq0.used + slot > (uint32_t)ARENA0_BYTES) {
-                            flush_bytes();
-                            o6 = 0u; n6 = 0x60u;
-                            (void)wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, nullptr, o6, n6);
-                        }
-                        ascii = wave_ascii_stage(a_short ? valB + b0 : valA + a0, nl, g_ar0 + bq0.used + TXT_PAD, o6, n6);
-                        if (ascii) {
+                        if (bq0.njobs == (uint32_t)LEV_JOBS || bq0.lanes + Bn > 64u || bq0.used + slot > (uint32_t)ARENA0_BYTES) flush_bytes();
+                        uint32_t o6 = job_or6, n6 = job_and6;
+                        if (wave_ascii_stage(a_short ? valA + a0 : valB + b0, ms, a_short ? valB + b0 : valA + a0, nl,
+                                             g_ar0 + bq0.used + TXT_PAD, o6, n6)) {
                             job_or6 = o6; job_and6 = n6;
                             if (lane == 0u)
                                 s_job[0][bq0.njobs] = BlockJob{a_short ? a0 : b0, (uint32_t)row, (uint16_t)ms, (uint16_t)nl,
