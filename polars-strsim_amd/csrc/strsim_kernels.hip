@@ -775,27 +775,62 @@ __device__ __forceinline__ bool lev_fits_symbols(const uint8_t *__restrict__ pa,
 __device__ __forceinline__ uint32_t wave_decode(const uint8_t *__restrict__ p, uint32_t len8, uint32_t *dst,
                                                 bool &nonascii)
 {
+    // Four byte positions per lane and trip (256 bytes of the string per trip, two loads per lane, both issued before anything
+    // waits), every position decoded without a branch: its byte and the three behind it lined up in one register, a continuation
+    // byte taken only if the lead byte asks for it AND it lies inside the string (a sequence cut off by the end of the string
+    // yields the bits it has, as the byte-per-lane loop of rounds 1-3 did -- which took a global round trip per 64 bytes and
+    // another for the continuation bytes: long non-ASCII rows cost 34 us each).  A value goes to dst[number of lead bytes in
+    // front of it].
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const uint32_t lane = lane_id();
     uint32_t base = 0;
-    for (uint32_t c0 = 0; c0 < len8; c0 += 64u) {
-        const uint32_t i = c0 + lane;
-        const bool in = i < len8;
-        const uint32_t b0 = in ? p[i] : 0x80u;
-        const bool lead = in && ((b0 & 0xC0u) != 0x80u);
-        const unsigned long long bal = __ballot(lead);
-        if (__ballot(in && b0 >= 0x80u) != 0ull) nonascii = true;
-        if (lead) {
-            uint32_t cp, need;
-            if (b0 < 0x80u) { cp = b0; need = 0; }
-            else if (b0 < 0xE0u) { cp = b0 & 0x1Fu; need = 1; }
-            else if (b0 < 0xF0u) { cp = b0 & 0x0Fu; need = 2; }
-            else { cp = b0 & 0x07u; need = 3; }
-            for (uint32_t k = 1; k <= need; ++k)
-                if (i + k < len8) cp = (cp << 6) | (p[i + k] & 0x3Fu);
-            dst[base + (uint32_t)__popcll(bal & lanemask_lt(lane))] = cp;
+    bool high = false;
+    for (uint32_t c0 = 0; c0 < len8; c0 += 256u) {
+        const uint32_t i = c0 + 4u * lane;
+        uint32_t d0 = 0u, d1 = 0u; // bytes i .. i + 7 (zeros behind the string)
+        if (i + 8u <= len8) {
+            d0 = *reinterpret_cast<const u32_unaligned *>(p + i);
+            d1 = *reinterpret_cast<const u32_unaligned *>(p + i + 4u);
+        } else if (i < len8) { // the string's last bytes, one by one: nothing is read behind a string
+            for (uint32_t k = 0; k < 8u && i + k < len8; ++k) {
+                const uint32_t by = p[i + k];
+                if (k < 4u) d0 |= by << (8u * k);
+                else d1 |= by << (8u * (k - 4u));
+            }
         }
-        base += (uint32_t)__popcll(bal);
+        uint32_t cp[4];
+        bool lead[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // w: byte q of the lane's window in byte 0, the three bytes behind it in bytes 1..3
+            const uint32_t w = q == 0 ? d0 : (uint32_t)__builtin_amdgcn_alignbyte(d1, d0, q);
+            const uint32_t pos = i + (uint32_t)q;
+            const uint32_t b0 = w & 0xFFu;
+            const bool in = pos < len8;
+            lead[q] = in && ((b0 & 0xC0u) != 0x80u);
+            high = high || (in && b0 >= 0x80u);
+            const uint32_t need = b0 < 0xC0u ? 0u : (b0 < 0xE0u ? 1u : (b0 < 0xF0u ? 2u : 3u)); // (0x80..0xBF are not leads)
+            uint32_t v = b0 < 0x80u ? b0 : (b0 < 0xE0u ? (b0 & 0x1Fu) : (b0 < 0xF0u ? (b0 & 0x0Fu) : (b0 & 0x07u)));
+#pragma unroll
+            for (int k = 1; k <= 3; ++k)
+                if ((uint32_t)k <= need && pos + (uint32_t)k < len8) v = (v << 6) | ((w >> (8 * k)) & 0x3Fu);
+            cp[q] = v;
+        }
+        uint32_t before = base; // lead bytes in front of this lane's first position
+        unsigned long long bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bal[q] = __ballot(lead[q]);
+            before += (uint32_t)__popcll(bal[q] & lanemask_lt(lane));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (lead[q]) dst[before] = cp[q];
+            before += lead[q] ? 1u : 0u;
+            base += (uint32_t)__popcll(bal[q]);
+        }
     }
+    if (__ballot(high) != 0ull) nonascii = true;
     __syncthreads();
     return base;
 }
