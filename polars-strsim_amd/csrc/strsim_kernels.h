@@ -22,7 +22,7 @@ constexpr int LEV_JOBS = STRSIM_LEV_JOBS;
 #endif
 constexpr int LEV_BYTES_ROWS = STRSIM_LEV_BYTES_ROWS;
 #ifndef STRSIM_LEV_POOL
-#define STRSIM_LEV_POOL 256 // rows ranked together before they are dealt into batches (a multiple of 64, at most 256)
+#define STRSIM_LEV_POOL 384 // rows ranked together before they are dealt into batches, at most (a multiple of 64; 16 bits of LDS per row)
 #endif
 constexpr int LEV_POOL = STRSIM_LEV_POOL;
 constexpr int TXT_PAD = 48;

@@ -1715,8 +1715,8 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
 #else
 #define STRSIM_WAVE_OCCUPANCY
 #endif
-#ifndef STRSIM_LEV_PLENTY_Q
-#define STRSIM_LEV_PLENTY_Q 2 // quarters of (waves x pool chunks) left on the list below which chunks are dealt one by one
+#ifndef STRSIM_LEV_SHARE_DIV
+#define STRSIM_LEV_SHARE_DIV 1 // a grab of k_wave_pairs<levenshtein> = what is left on the list / (waves x this), at most a pool
 #endif
 template <int MEASURE>
 __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
@@ -1822,12 +1822,18 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
     const uint32_t C = status->list_count[MEASURE], R = status->list_rows[MEASURE];
     const uint32_t budget = (R >> 6) > 8192u ? (R >> 6) : 8192u;
     const uint32_t grab = C / budget >= 64u ? 64u : (C / budget ? C / budget : 1u);
-    // Levenshtein pools the rows of up to LEV_POOL / 64 chunks: it takes that many entries at a time while plenty of work is
-    // left behind the grab -- it looks at the counter first --; the tail of the list is dealt chunk by chunk, so that the waves
-    // still finish together (a pool of four dense chunks of cfg5 is a quarter of a wave's whole share).
-    const uint32_t big = (LEV && grab < (uint32_t)(LEV_POOL / 64)) ? (uint32_t)(LEV_POOL / 64) : grab;
-    const uint32_t plenty = gridDim.x * big * (uint32_t)STRSIM_LEV_PLENTY_Q / 4u;
-    const uint32_t g0 = C > gridDim.x * big + plenty ? big : grab; // the static first grab
+    // Levenshtein pools the rows of up to LEV_POOL / 64 chunks: a wave takes that many entries at a time while the list is long,
+    // and fewer as it runs out -- what is left (it reads the counter first) divided by the waves, at least `grab` -- so that most
+    // rows are ranked in full pools and the waves still finish together (a pool of dense chunks of cfg5 is a third of a wave's
+    // whole share; deciding by the wave's own previous grab, one round stale, dealt everything in full pools: + 10 %).
+    // A full pool is a third of a wave's share of the list at most (cfg5 at 10 M rows has 15 chunks per wave: pools of five; at
+    // 7 M rows, 10.7 per wave, pools of six lost 4 % to the waves' last grabs and pools of three lost nothing).
+    uint32_t big = grab;
+    if (LEV && grab < (uint32_t)(LEV_POOL / 64)) {
+        big = C / (gridDim.x * 3u);
+        big = big > (uint32_t)(LEV_POOL / 64) ? (uint32_t)(LEV_POOL / 64) : (big > grab ? big : grab);
+    }
+    const uint32_t g0 = big; // the static first grab
     for (uint32_t round = 0;; ++round) {
         uint32_t got = blockIdx.x * g0, take = g0;
         if (round != 0u) {
@@ -1835,7 +1841,8 @@ __global__ __launch_bounds__(64) STRSIM_WAVE_OCCUPANCY void k_wave_pairs(const u
                 take = grab;
                 if (big != grab) {
                     const uint32_t at = __hip_atomic_load(&status->next_entry[MEASURE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gridDim.x * g0;
-                    if (C > at && C - at > plenty) take = big;
+                    const uint32_t share = C > at ? (C - at) / (gridDim.x * (uint32_t)STRSIM_LEV_SHARE_DIV) : 0u;
+                    take = share >= big ? big : (share > grab ? share : grab);
                 }
                 got = atomicAdd(&status->next_entry[MEASURE], take);
             }
