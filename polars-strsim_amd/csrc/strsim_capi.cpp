@@ -57,7 +57,7 @@ struct strsim_ctx {
     int num_cu = 0;
     int stage_wg_per_cu = 5;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pairs instead of k_lane_stage (A/B runs)
     int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
-    int lev_waves_per_cu = 20; // five per SIMD (96 VGPRs, 6.7 KB of LDS); STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
+    int lev_waves_per_cu = 20; // five per SIMD (96 VGPRs, 7.6 KB of LDS = six 1 280-byte granules); STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
     // workspace (grow-only).  The "not finished yet" masks (+ backup + work list) of a call: a ring of MASKBUFS buffers, slot s
     // uses buffer s % MASKBUFS -- a call whose slow-row kernels are launched late (below) needs its mask intact while
     // younger calls run
