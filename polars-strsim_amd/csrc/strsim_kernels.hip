@@ -291,7 +291,7 @@ constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
 constexpr int WIDE_SPAN = STRSIM_WIDE_SPAN;  // mask words (64-row chunks) per span of k_lane_wide
 constexpr int WIDE_ROWS = WIDE_SPAN * 64;    // 4096 rows
 #ifndef STRSIM_WIDE_LIST
-#define STRSIM_WIDE_LIST 6144 // rows on k_lane_wide's sorted list (at least WIDE_ROWS): 12 KB, what the LDS of three workgroups per CU has left
+#define STRSIM_WIDE_LIST 8192 // rows on k_lane_wide's sorted list (at least WIDE_ROWS): 16 KB, what the LDS of three workgroups per CU has left
 #endif
 constexpr int WIDE_LIST = STRSIM_WIDE_LIST;
 static_assert(WIDE_LIST >= WIDE_ROWS && WIDE_BLOCK * 64 <= 65536, "one span always fits the list; list entries are 16-bit row indices of a super");
@@ -331,13 +331,20 @@ struct LdsTxt {
     const uint32_t *col; // &s_txt[wave][0][lane], dword g at col[g * 64]
     __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return col[g * 64u]; }
 };
-struct LdsFaStore {
-    uint32_t *col;
-    __device__ __forceinline__ void operator()(uint32_t q, uint32_t v) const { col[q * 64u] = v; }
-};
-struct LdsFaLoad {
-    const uint32_t *col;
-    __device__ __forceinline__ uint32_t operator()(uint32_t q) const { return col[q * 64u]; }
+// Jaro's string of matched characters (strsim_lane_wide.h): byte k of the lane's text column -- dword k / 4 at col[(k / 4) * 64]
+struct LdsSa {
+    uint32_t base; // LDS byte address of the lane's column (a multiple of 4)
+    __device__ __forceinline__ uint32_t at(uint32_t k) const { return ((k >> 2) << 8) + ((k & 3u) | base); } // three instructions
+    // Unconditional: a character that found no partner is overwritten by the next one that does (k does not move), and what
+    // is left behind the last match is never read.
+    __device__ __forceinline__ void put(uint32_t k, uint32_t c, uint32_t) const
+    {
+        *reinterpret_cast<__attribute__((address_space(3))) uint8_t *>((uintptr_t)at(k)) = (uint8_t)c;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t k) const
+    {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)at(k));
+    }
 };
 
 // max over the wave of v (v <= 255), uniform
@@ -353,8 +360,7 @@ __device__ __forceinline__ uint32_t wave_max_u8(uint32_t v)
 template <int MEASURE, int W>
 __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
-                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t *txt_col, uint32_t *fa_col,
-                                           bool &done, double &res)
+                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t *txt_col, bool &done, double &res)
 {
     uint32_t ta[8 * W], wp[8 * W];
 #pragma unroll
@@ -384,12 +390,13 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
     const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
     const LdsTxt txt{txt_col};
-    const LdsFaStore fst{fa_col};
-    const LdsFaLoad fld{fa_col};
+    const LdsSa sa{STRSIM_LDS_ADDR(txt_col)};
+    // Jaro's second pass walks b: as far as the round's longest one reaches
+    const uint32_t nb4 = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? (wave_max_u8(fast ? lb : 0u) + 3u) >> 2 : 0u;
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation, cf. k_lane_pairs)
     __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
-    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, ta[0], b0w, fst, fld);
-    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, ta[0], b0w, fst, fld);
+    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
+    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
     __builtin_amdgcn_s_setprio(1);
     done = fast;
 }
@@ -415,13 +422,14 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     // 64 rows at a time.  The longer the list, the more alike the rows of a round: cfg3's rounds ran 74 % of their
     // lane-columns on a row that needed them with lists of one span (4 096 rows, 24 keys of 8 / 16 columns), 90 % with the whole
     // super and keys of 4 columns.  A super whose candidates do not fit the list (WIDE_LIST entries) is done span by span.
-    constexpr int NKEY = 96;                    // 3 width classes (masks of 2 / 3 / 4 words) x 32 column counts (4 columns each)
+    // 3 width classes (masks of 2 / 3 / 4 words) x 32 column counts (4 columns each) x 4 quarters of the pattern length (Jaro's
+    // second pass walks the pattern as far as the round's longest one reaches)
+    constexpr int NKEY = 384, KPL = NKEY / 64;
     __shared__ unsigned long long s_mask[WIDE_BLOCK];
     __shared__ uint32_t s_cnt[NKEY];            // rows per key, then the key's next free list position
     __shared__ uint32_t s_next, s_total;        // next round to hand out; rows on the list
     __shared__ uint16_t s_list[WIDE_LIST];      // candidate rows (index within the super), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
-    __shared__ uint32_t s_fa[WIDE_WAVES][WIDE_MAXW + 1][64];
 
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int RPS = WIDE_ROWS / WIDE_BLOCK; // rows per thread and span in the collection phase
@@ -443,24 +451,24 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
       s_mask[tid] = myword;
       uint32_t gsz = sps; // spans per list: the whole super, or one at a time when that does not fit
       for (uint32_t g0 = 0; g0 < sps;) {
-        if (tid < (uint32_t)NKEY) s_cnt[tid] = 0u;
-        if (tid == (uint32_t)NKEY) s_next = 0u;
+        for (uint32_t q = tid; q < (uint32_t)NKEY; q += (uint32_t)WIDE_BLOCK) s_cnt[q] = 0u;
+        if (tid == 0u) s_next = 0u;
         lds_barrier();
         // ---- key of a flagged row: 33..128-byte strings on the longer side and a non-empty shorter side; width class, then the
         //      number of DP columns (the text length).  The keys wait for the second pass in the text columns' LDS, idle until
         //      the rounds start (64 keys per thread in registers cost more than the kernel has: 1.6 KB of scratch per lane).
-        uint8_t *const s_key = reinterpret_cast<uint8_t *>(&s_txt[0][0][0]);
-        static_assert(sizeof(s_txt) >= (size_t)WIDE_BLOCK * 64, "a key byte per row of a super");
-        auto row_key = [&](uint32_t i) -> uint32_t { // 0x7F: not a candidate
-            if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0x7Fu;
+        uint16_t *const s_key = reinterpret_cast<uint16_t *>(&s_txt[0][0][0]);
+        static_assert(sizeof(s_txt) >= (size_t)WIDE_BLOCK * 64 * 2, "a 16-bit key per row of a super");
+        auto row_key = [&](uint32_t i) -> uint32_t { // 0xFFFF: not a candidate
+            if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0xFFFFu;
             const uint64_t row = cw0 * 64u + i;
             const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
             const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
             const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
-            if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0x7Fu;
-            const uint32_t steps = SYMMETRIC ? mn : la8;
+            if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0xFFFFu;
+            const uint32_t steps = SYMMETRIC ? mn : la8, pat = SYMMETRIC ? mx : lb8;
             const uint32_t cls = mx > 96u ? 2u : (mx > 64u ? 1u : 0u); // masks of 4 / 3 / 2 words
-            return cls * 32u + ((steps - 1u) >> 2);
+            return (cls * 32u + ((steps - 1u) >> 2)) * 4u + (pat - 1u) / (8u * (cls + 2u));
         };
 #pragma unroll 1
         for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
@@ -468,25 +476,25 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
             for (int kk = 0; kk < RPS; ++kk) {
                 const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
                 const uint32_t key = row_key(i);
-                s_key[i] = (uint8_t)key;
-                if (key != 0x7Fu) atomicAdd(&s_cnt[key], 1u);
+                s_key[i] = (uint16_t)key;
+                if (key != 0xFFFFu) atomicAdd(&s_cnt[key], 1u);
             }
         }
         lds_barrier();
-        // ---- list positions: exclusive prefix sum of the 96 counters (wave 0, two keys per lane)
+        // ---- list positions: exclusive prefix sum of the counters (wave 0, KPL keys per lane)
         if (wv == 0u) {
-            const uint32_t c0k = lane < (uint32_t)(NKEY / 2) ? s_cnt[2u * lane] : 0u;
-            const uint32_t c1k = lane < (uint32_t)(NKEY / 2) ? s_cnt[2u * lane + 1u] : 0u;
-            uint32_t inc = c0k + c1k;
+            uint32_t c[KPL], sum = 0u;
+#pragma unroll
+            for (int q = 0; q < KPL; ++q) { c[q] = s_cnt[(uint32_t)KPL * lane + (uint32_t)q]; sum += c[q]; }
+            uint32_t inc = sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t up = (uint32_t)__shfl_up((int)inc, d);
                 if (lane >= (uint32_t)d) inc += up;
             }
-            if (lane < (uint32_t)(NKEY / 2)) {
-                s_cnt[2u * lane] = inc - c0k - c1k;
-                s_cnt[2u * lane + 1u] = inc - c1k;
-            }
+            uint32_t base = inc - sum;
+#pragma unroll
+            for (int q = 0; q < KPL; ++q) { s_cnt[(uint32_t)KPL * lane + (uint32_t)q] = base; base += c[q]; }
             if (lane == 63u) s_total = inc;
         }
         lds_barrier();
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 for (int kk = 0; kk < RPS; ++kk) {
                     const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
                     const uint32_t key = s_key[i];
-                    if (key != 0x7Fu) s_list[atomicAdd(&s_cnt[key], 1u)] = (uint16_t)i;
+                    if (key != 0xFFFFu) s_list[atomicAdd(&s_cnt[key], 1u)] = (uint16_t)i;
                 }
             }
             lds_barrier();
@@ -538,11 +546,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 bool done = false;
                 double res = 0.0;
                 if (!wide3)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
                 else if (!wide4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
                 else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], &s_fa[wv][0][lane], done, res);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
                 if (done) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));

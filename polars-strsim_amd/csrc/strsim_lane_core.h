@@ -15,6 +15,7 @@
 // and the f64 epilogues, in the reference's operation order (compile with -ffp-contract=off).
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define STRSIM_HD __host__ __device__ __forceinline__
@@ -37,6 +38,18 @@ constexpr int COLS_PER_TEST = STRSIM_COLS_PER_TEST;
 STRSIM_HD uint32_t lane_byte(const uint32_t (&w)[8], int j) { return (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu; }
 
 STRSIM_HD uint32_t low_ones(uint32_t k) { return k >= 32u ? 0xFFFFFFFFu : ((1u << k) - 1u); }
+
+// for (g = G; g < NG; ++g) if (!f(integral_constant<g>)) break;  -- unrolled by construction (the column loops index
+// registers with g: left to `#pragma unroll` a loop with an early exit may stay rolled, and then every register array becomes
+// a chain of selects)
+template <int G, int NG, typename F>
+STRSIM_HD void unrolled_until(F &&f)
+{
+    if constexpr (G < NG) {
+        if (f(std::integral_constant<int, G>{})) unrolled_until<G + 1, NG>(f);
+    }
+}
+
 
 STRSIM_HD uint32_t popc32(uint32_t x)
 {

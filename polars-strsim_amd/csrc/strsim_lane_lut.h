@@ -28,17 +28,6 @@
 
 namespace strsim {
 
-// for (g = G; g < NG; ++g) if (!f(integral_constant<g>)) break;  -- unrolled by construction (the column loops index
-// registers with g: left to `#pragma unroll` a loop with an early exit may stay rolled, and then every register array becomes
-// a chain of selects)
-template <int G, int NG, typename F>
-STRSIM_HD void unrolled_until(F &&f)
-{
-    if constexpr (G < NG) {
-        if (f(std::integral_constant<int, G>{})) unrolled_until<G + 1, NG>(f);
-    }
-}
-
 #ifndef STRSIM_LUT_AHEAD
 #define STRSIM_LUT_AHEAD 1 // groups of COLS_PER_TEST columns between a table read and its use
 #endif

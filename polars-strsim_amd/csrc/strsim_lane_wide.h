@@ -288,19 +288,24 @@ STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Jaro matching, W words.  Pattern = b (right-aligned planes: bit j = b[j]), text = a through txt().
-// `fa_store(q, word)` / `fa_load(q)` keep the flagged-a bits of columns [32q, 32q+32) between the two
-// passes (an LDS column per lane on the GPU).  la, lb >= 1.  Returns m and t (not halved).
+// Jaro matching, W words.  Pattern = b (right-aligned planes: bit j = b[j]; wp = its bytes), text = a through txt().
+// la, lb >= 1; nb4 = dwords of b to walk in the second pass (>= ceil(lb / 4), uniform).  Returns m and t (not halved).
+//
+// Transpositions [r3]: the characters of the matched a_i are collected, in the order of a, as a byte string SA -- `sa.put(k, c,
+// hit)` stores c at position k if hit, `sa.get(k)` reads position k; on the GPU SA overwrites the front of the text column in
+// LDS (there are never more matches than columns walked, and a group's four characters are in a register before its columns
+// run) --, and the second pass walks b: the k-th flagged b_j against SA[k] (strsim.rs:222-233 zips exactly these two
+// sequences; `put` may ignore `hit`: a character stored at k without a match is overwritten by the next match, k not having
+// moved).  Rounds 1-2 walked a again and rebuilt every column's match mask to test one bit of it: 9 + 9 W instructions
+// per column of a against about ten per position of b here, and the flags of a (kept in LDS between the passes) are gone.
 // ---------------------------------------------------------------------------------------------
-template <int NP, int W, class Txt, class FaStore, class FaLoad>
-STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W],
-                         const FaStore &fa_store, const FaLoad &fa_load, uint32_t &m_out, uint32_t &t_out)
+template <int NP, int W, class Txt, class Sa>
+STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, uint32_t nb4, const uint32_t (&P)[NP][W],
+                         const uint32_t (&wp)[8 * W], const Sa &sa, uint32_t &m_out, uint32_t &t_out)
 {
     // Instruction diet: the two window masks move along as carry chains (himask is not clamped to lb -- the
     // match masks already are), "this column is past the end of a" is the sign of a running counter, the lowest candidate is
-    // folded into the flags with one three-input op per word, and the "a_i found a partner" bits are shifted in from the
-    // right by an add-with-carry (column c of a 32-column group ends at bit 31 - c; the second pass reads them from the top
-    // with an arithmetic shift).
+    // folded into the flags with one three-input op per word.
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u;
@@ -309,7 +314,7 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
     low_ones_wide<W>(bound + 1u, himask); // ones at [0, i + bound]
 #pragma unroll
     for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
-    uint32_t fa_acc = 0u;
+    uint32_t m = 0u;
     uint32_t left = la - 1u; // la - 1 - i: negative from column la on
     for (uint32_t g = 0; g < ng4; ++g) {
         const uint32_t c4 = txt(g);
@@ -328,41 +333,31 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
             minus1_wide(cand, d);
 #pragma unroll
             for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
-            fa_acc = shl1_nz(fa_acc, any_wide<W>(cand));
+            const uint32_t hit = any_wide<W>(cand);
+            sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
+            m = add_nz(m, hit);
             shl1_one(himask);
             shl1_ge(lomask, i, bound);
         }
-        if ((g & 7u) == 7u) { fa_store(g >> 3, fa_acc); fa_acc = 0u; }
     }
-    if ((ng4 & 7u) != 0u) fa_store(ng4 >> 3, fa_acc << (32u - 4u * (ng4 & 7u))); // partial last group: top-align
-
-    uint32_t rest[W];
+    uint32_t t = 0u, k = 0u;
+    unrolled_until<0, 8 * W>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if ((uint32_t)g >= nb4) return false;
+        const uint32_t word = wp[g];
+        constexpr int j0 = 4 * g;
+        // the four positions of this dword: flags and SA positions first, so that the four reads are in flight together
+        uint32_t fl[4], ach[4];
 #pragma unroll
-    for (int w = 0; w < W; ++w) rest[w] = fb[w];
-    uint32_t t = 0u, fa_cur = 0u;
-    for (uint32_t g = 0; g < ng4; ++g) {
-        if ((g & 7u) == 0u) fa_cur = fa_load(g >> 3);
-        const uint32_t c4 = txt(g);
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t on = sign_fill(fa_cur); // a_i was matched
-            fa_cur += fa_cur;
-            uint32_t Eq[W], d[W];
-            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
-            minus1_wide(rest, d);
-            uint32_t miss = 0u;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t jbit = bitop3<0x20>(rest[w], d[w], on); // lowest remaining flag of b, if a_i is matched
-                rest[w] = bitop3<0xD0>(rest[w], d[w], on);             // rest & (d | ~on): that flag is used up
-                miss = bitop3<0xF4>(miss, jbit, Eq[w]);                // miss | (jbit & ~Eq)
-            }
-            t = add_nz(t, miss);
+        for (int jj = 0; jj < 4; ++jj) {
+            fl[jj] = (fb[j0 >> 5] >> ((j0 & 31) + jj)) & 1u; // b_j was matched
+            ach[jj] = sa.get(k);
+            k += fl[jj];
         }
-    }
-    uint32_t m = 0u;
 #pragma unroll
-    for (int w = 0; w < W; ++w) m += popc32(fb[w]);
+        for (int jj = 0; jj < 4; ++jj) t += ach[jj] != ((word >> (8 * jj)) & 0xFFu) ? fl[jj] : 0u;
+        return true;
+    });
     m_out = m;
     t_out = t;
 }
@@ -400,11 +395,12 @@ STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_
 // ---------------------------------------------------------------------------------------------
 // One lane's result, strings of 1..32*W ASCII bytes each (the empty cases never reach the wide path).
 // wp = the pattern window: the 32W bytes that START at b.  a0w / b0w = first dwords of a and b (Jaro-Winkler prefix).
-// gfull <= la / 4 for every lane of the wave (text dwords in which no lane's text ends), ng4 = text dwords to walk.
+// gfull <= la / 4 for every lane of the wave (text dwords in which no lane's text ends), ng4 = text dwords to walk, nb4 = pattern
+// dwords to walk (Jaro's second pass); sa: see jaro_wide.
 // ---------------------------------------------------------------------------------------------
-template <int MEASURE, int NP, int W, class Txt, class FaStore, class FaLoad>
+template <int MEASURE, int NP, int W, class Txt, class Sa>
 STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const uint32_t (&wp)[8 * W], uint32_t lb,
-                                  uint32_t a0w, uint32_t b0w, const FaStore &fa_store, const FaLoad &fa_load)
+                                  uint32_t nb4, uint32_t a0w, uint32_t b0w, const Sa &sa)
 {
     uint32_t P[NP][W];
     build_planes_wide<NP, W>(wp, P);
@@ -412,7 +408,7 @@ STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t gfull, u
         return epilogue_levenshtein(lev_wide<NP, W>(txt, la, gfull, ng4, P, lb), la, lb);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
-        jaro_wide<NP, W>(txt, la, ng4, lb, P, fa_store, fa_load, m, t);
+        jaro_wide<NP, W>(txt, la, ng4, lb, nb4, P, wp, sa, m, t);
         const double j = epilogue_jaro(m, t, la, lb);
         return MEASURE == JARO ? j : epilogue_jaro_winkler(j, common_prefix4(a0w, la, b0w, lb));
     } else {

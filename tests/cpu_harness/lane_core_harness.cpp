@@ -3,6 +3,7 @@
 // GPU.  Test infrastructure only.
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include "strsim_lane_core.h"
 #include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
@@ -163,17 +164,23 @@ extern "C" int harness_check_planes(const uint8_t *bytes32)
 
 // ---- wide (W-word) cores -------------------------------------------------------------------------
 struct ArrTxt { const uint32_t *w; uint32_t operator()(uint32_t g) const { return w[g]; } };
-struct FaSt { uint32_t *f; void operator()(uint32_t q, uint32_t v) const { f[q] = v; } };
-struct FaLd { const uint32_t *f; uint32_t operator()(uint32_t q) const { return f[q]; } };
+// Jaro's string of matched characters overwrites the front of the text, as on the GPU (the text column in LDS)
+struct ArrSa {
+    uint8_t *bytes;
+    void put(uint32_t k, uint32_t c, uint32_t) const { bytes[k] = (uint8_t)c; } // unconditional, as on the GPU
+    uint32_t get(uint32_t k) const { return bytes[k]; }
+};
 
 template <int M, int NP, int W>
-static double run_wide_np(const uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w)
+static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w)
 {
-    uint32_t fa[W + 1] = {0};
     const uint32_t ng4 = (la + 3u) / 4u;
+    // (nb4: any value from ceil(lb / 4) up to the window: the kernel passes the wave's maximum)
+    const uint32_t nb4 = std::min<uint32_t>(8u * W, (lb + 3u) / 4u + ((la * 7u + lb) % 3u));
+    const uint32_t a0w = ta[0];
     // (gfull: any value up to la / 4; the kernel passes the wave's minimum -- sweep it through a few)
     const uint32_t gfull = (la / 4u) * ((la ^ lb) & 3u) / 3u;
-    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, ta[0], b0w, FaSt{fa}, FaLd{fa});
+    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, nb4, a0w, b0w, ArrSa{reinterpret_cast<uint8_t *>(ta)});
 }
 
 template <int M, int W>
