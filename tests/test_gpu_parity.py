@@ -204,8 +204,9 @@ def test_long_levenshtein_rows_pooled_across_chunks(S, monkeypatch, waves):
 @pytest.mark.parametrize("density", [0.3, 0.55, 1.0])
 @pytest.mark.parametrize("measure", O.MEASURES)
 def test_wide_rows_at_every_list_density(S, ctx, measure, density):
-    """k_lane_wide sorts the 33..128-byte rows of a 16 384-row super-span into one list when they fit it (6 144 rows), of half
-    a super when those do, else span by span: frames with 30 %, 55 % and 100 % of such rows take the three paths."""
+    """k_lane_wide sorts the 33..128-byte rows of a 16 384-row super-span into one list when they fit it (8 192 rows), else half a
+    super at a time: frames with 30 % of such rows take the first path, with 55 % and 100 % the second (after a counting pass that
+    found them too many)."""
     import random
     rng = random.Random(int(density * 100))
     A, B = [], []
