@@ -182,8 +182,9 @@ def main():
     ctx = S.Context(local_rank, stream=compute_stream.cuda_stream)
     assert ctx.stream == compute_stream.cuda_stream
     gather = world > 1 and not a.no_gather
-    if gather:
-        ctx.set_stream_ordered(True)  # the gather reads a step's results behind an event, without retiring the call first
+    # A step's results are only read after ctx.synchronize() when nothing is gathered: one-launch calls (ABI 1.4 opt-in).  The
+    # gather reads a step's results behind an event, without retiring the call first: it needs the default, stream-ordered mode.
+    ctx.set_stream_ordered(bool(gather))
     shipper = None
     gather_note = None
     if gather:

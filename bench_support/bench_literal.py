@@ -22,7 +22,7 @@ lit_off = torch.from_numpy(lo_.view(np.int32)).to(dev)
 lit_val = torch.from_numpy(np.concatenate([lv_, np.zeros(64, np.uint8)])).to(dev)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
-ctx = S.Context(0, stream=st.cuda_stream)
+ctx = S.Context(0, stream=st.cuda_stream, one_launch=True)
 for m in S.MEASURES:
     for name, args in (("col,col", (offA, valA, offB, valB)), ("col,lit", (offA, valA, lit_off, lit_val)),
                        ("lit,col", (lit_off, lit_val, offB, valB))):

@@ -28,7 +28,7 @@ def cyr(off, val):
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
-ctx = S.Context(0, stream=st.cuda_stream)
+ctx = S.Context(0, stream=st.cuda_stream, one_launch=True)
 t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
 pad = np.zeros(64, dtype=np.uint8)
 cells = float((np.diff(oa.astype(np.int64)) * np.diff(ob.astype(np.int64))).sum())

@@ -17,7 +17,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
-ctx = S.Context(0, stream=st.cuda_stream)
+ctx = S.Context(0, stream=st.cuda_stream, one_launch=True)
 oa, va, ob, vb, _, _ = W.device_columns(33, W.UNIFORM, 33, 128, 0, rows, dev)
 out = torch.empty(rows, dtype=torch.float64, device=dev)
 for m in S.MEASURES:

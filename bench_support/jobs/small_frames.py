@@ -8,7 +8,7 @@ from bench_support import workload as W
 dev = torch.device("cuda", 0)
 m, _, law, lo, hi, seed = W.CONFIGS["cfg1"]
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
-ctx = S.Context(0, stream=st.cuda_stream)
+ctx = S.Context(0, stream=st.cuda_stream, one_launch=True)
 for rows in [int(x) for x in os.environ.get('ROWS', '1000,10000,100000,300000,1000000,3000000,10000000').split(',')]:
     oa, va, ob, vb, _, _ = W.device_columns(seed, law, lo, hi, 0, rows, dev)
     out = torch.empty(rows, dtype=torch.float64, device=dev)

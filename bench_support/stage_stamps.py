@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle sums of k_lane_stage (library built with -DSTRSIM_STAGE_STAMPS, selected by STRSIM_AMD_LIB)."""
+"""Diagnostic: per-phase cycle sums of k_lane_stage (library built with EXTRA="-DSTRSIM_LAB -DSTRSIM_STAGE_STAMPS", selected by STRSIM_AMD_LIB)."""
 import ctypes as C
 import os
 import sys

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010003u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows) */
+#define STRSIM_ABI_VERSION 0x00010004u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2 */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -100,16 +100,23 @@ STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
  * Results are complete after strsim_ctx_synchronize() (or strsim_ctx_retire_oldest() of this call).
  * All buffers of a call must stay valid until then.
  *
- * What the stream alone guarantees (ABI 1.3): a context whose last retired call had every row finished
- * by the one-pair-per-lane kernel (both strings <= STRSIM_LANE_PATH_MAX_BYTES, ASCII -- the common
- * column) enqueues the NEXT call as that kernel alone: ONE launch instead of five.  If such a call
- * does hold longer or non-ASCII rows, the kernels for them are launched when the call is retired, i.e.
- * AFTER anything the caller enqueued behind the call -- strsim_ctx_last_late_rows() tells, and the calls
- * after it enqueue all their kernels up front again.  A caller that consumes results in stream order
- * without retiring the call first (a collective on a side stream behind an event) switches this off with
- * strsim_ctx_set_stream_ordered(ctx, 1): then every row of strings <= STRSIM_WAVE_PATH_MAX_BYTES is
- * complete in stream order, as in ABI 1.2; rows with a longer string are always finished by a pass that
- * strsim_ctx_synchronize() / strsim_ctx_retire_oldest() launches.
+ * What the stream alone guarantees: every row of strings <= STRSIM_WAVE_PATH_MAX_BYTES is complete in stream
+ * order (work enqueued on strsim_ctx_stream() behind the call sees it); rows with a longer string are always
+ * finished by a pass that strsim_ctx_synchronize() / strsim_ctx_retire_oldest() launches
+ * (strsim_ctx_last_long_rows() tells).
+ *
+ * One-launch calls (opt-in since ABI 1.4: strsim_ctx_set_stream_ordered(ctx, 0)): a context whose last retired
+ * call had every row finished by the one-pair-per-lane kernel (both strings <= STRSIM_LANE_PATH_MAX_BYTES, ASCII
+ * -- the common column) enqueues the NEXT call as that kernel alone: ONE launch instead of five.  If such a call
+ * does hold longer or non-ASCII rows, the kernels for them are launched when the call is retired, i.e. AFTER
+ * anything the caller enqueued behind the call -- strsim_ctx_last_late_rows() tells, and the calls after it enqueue
+ * all their kernels up front again.  For callers that retire every call (strsim_ctx_retire_oldest /
+ * strsim_ctx_synchronize) before they consume its results, and look at strsim_ctx_last_late_rows() if they copied
+ * results out early: the plugin layer does.  A pending one-launch call owns a "not finished yet" mask (20 bytes per 64 rows)
+ * until it is retired, so a caller that keeps k calls in flight holds k of them.  The library never retires a call the
+ * caller has not asked it to, except when more than 32 calls are in flight on one context: then everything pending is
+ * retired inside strsim_pairs_device (a stream synchronise) and what that finished late is added to the next
+ * retirement's strsim_ctx_last_late_rows().
  */
 STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
@@ -138,8 +145,9 @@ STRSIM_API int strsim_pairs_device_all(strsim_ctx_t *ctx,
 /* Wait for everything enqueued through this context and surface any deferred error. */
 STRSIM_API int strsim_ctx_synchronize(strsim_ctx_t *ctx);
 
-/* 1: every call enqueues all its kernels up front (results of rows <= STRSIM_WAVE_PATH_MAX_BYTES complete in stream order);
- * 0 (default): calls that are expected to need the first kernel only are one launch (see strsim_pairs_device). */
+/* 1 (default): every call enqueues all its kernels up front (results of rows <= STRSIM_WAVE_PATH_MAX_BYTES complete in stream
+ * order); 0: calls that are expected to need the first kernel only are one launch (see strsim_pairs_device).  Takes effect
+ * with the next call; calls already pending keep the mode they were enqueued in. */
 STRSIM_API int strsim_ctx_set_stream_ordered(strsim_ctx_t *ctx, int enable);
 
 /*

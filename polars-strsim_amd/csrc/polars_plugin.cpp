@@ -641,6 +641,9 @@ struct Pipe {
         if (!ctx) {
             device = dev;
             if (strsim_ctx_create(device, nullptr, &ctx) != STRSIM_OK) fail(strsim_last_error_message());
+            // one-launch calls (ABI 1.4 opt-in): every slice is retired before its results are handed on, and a slice whose
+            // slow rows were finished at retirement is fetched again (strsim_ctx_last_late_rows below)
+            if (strsim_ctx_set_stream_ordered(ctx, 0) != STRSIM_OK) fail(strsim_last_error_message());
             lit_off.device = lit_val.device = true;
         }
         HIP_OR_FAIL(hipSetDevice(device));

@@ -4,7 +4,6 @@
 // (reference src/expressions/strsim.rs:41-107): shape rule, literal broadcast, row partition.
 // There is no CPU compute path in this library: without a HIP device every compute call fails.
 #include <hip/hip_runtime.h>
-#include <sched.h>
 #include <algorithm>
 
 #include <cstdarg>
@@ -55,18 +54,21 @@ struct strsim_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
-    int stage_wg_per_cu = 5;  // STRSIM_STAGE_WG_PER_CU overrides; 0 = k_lane_pairs instead of k_lane_stage (A/B runs)
-    int lane_wg_per_cu = 128; // STRSIM_LANE_WG_PER_CU overrides (tuning knob): ~10x the 6 resident workgroups, see DESIGN 3.1
+    int stage_wg_per_cu = 5;  // resident workgroups of k_lane_stage per CU; STRSIM_STAGE_WG_PER_CU overrides (tuning knob)
     int lev_waves_per_cu = 20; // five per SIMD (96 VGPRs, 7.6 KB of LDS = six 1 280-byte granules); STRSIM_LEV_WAVES_PER_CU overrides (tuning knob)
-    // workspace (grow-only).  The "not finished yet" masks (+ backup + work list) of a call: a ring of MASKBUFS buffers, slot s
-    // uses buffer s % MASKBUFS -- a call whose slow-row kernels are launched late (below) needs its mask intact while
-    // younger calls run
-    static constexpr int MASKBUFS = 4;
-    unsigned long long *slowmask[MASKBUFS] = {};
-    size_t slowmask_cap[MASKBUFS] = {}; // bytes
     // per-call deferred state: a ring of status words + event triples, so calls can be enqueued
     // back to back without a host sync; the ring is drained by strsim_ctx_synchronize()
     static constexpr int RING = 32;
+    // workspace (grow-only).  The "not finished yet" masks (+ backup + work list) of a call.  A call whose slow-row kernels may be
+    // launched late (a one-launch call, below) needs its mask intact while younger calls run: it OWNS one of the first RING
+    // buffers (the lowest free one; allocated on first use, so a caller that keeps k calls in flight touches k of them) until it is
+    // retired.  Calls that enqueue all their kernels up front share the last buffer (they use it in stream order).  Nothing is ever
+    // retired behind the caller's back to make room: a buffer is always free while a ring slot is.
+    static constexpr int MASKBUFS = RING + 1;
+    static constexpr int SHARED_MASKBUF = MASKBUFS - 1;
+    unsigned long long *slowmask[MASKBUFS] = {};
+    size_t slowmask_cap[MASKBUFS] = {}; // bytes
+    int maskbuf_owner[MASKBUFS];        // ring slot of the pending one-launch call that owns the buffer, or -1 (set in strsim_ctx_create)
     DevStatus *status = nullptr;      // device, RING entries
     uint32_t *sched = nullptr;        // device, RING x 4 words: work-distribution counters of k_lane_stage (zero between launches)
     DevStatus *status_host = nullptr; // pinned, RING entries
@@ -83,8 +85,10 @@ struct strsim_ctx {
     bool slot_deferred[RING] = {};
     bool expect_slow = false;
     bool long_rows = false;        // ... and left more than 1/16 of its rows: frames of long strings (see k_lane_stage, TABLES)
-    bool stream_ordered = false;   // strsim_ctx_set_stream_ordered: never defer
+    bool stream_ordered = true;    // strsim_ctx_set_stream_ordered(ctx, 0) opts in to one-launch calls
     uint64_t last_late_rows = 0;   // rows finished by a pass launched from synchronize / retire (deferred + long-string)
+    uint64_t carry_late_rows = 0, carry_long_rows = 0; // the same of calls the library had to retire itself (the ring of status
+                                   // slots wrapped): reported with the caller's next strsim_ctx_synchronize / _retire_oldest
     hipEvent_t ev_late[2] = {};    // timing of a deferred slow pass
     uint64_t enqueued_ops = 0;     // kernels + copies this context has put on its stream for pair calls (strsim_ctx_enqueued_ops)
     uint32_t slot_ticket[RING] = {}; // what the device writes into status_host[slot].ticket when the call's status block is out
@@ -173,19 +177,7 @@ static bool ctx_slot_published(const strsim_ctx *c, int s)
     return seen == c->slot_ticket[s];
 }
 
-// Wait until the call in slot s has completed (its ticket has arrived), without waiting for younger calls: poll the
-// host-mapped ticket for a while, then fall back on the stream.
-static int ctx_wait_published(strsim_ctx *c, int s)
-{
-    for (int spin = 0; spin < 2000000; ++spin) {
-        if (ctx_slot_published(c, s)) return STRSIM_OK;
-        if ((spin & 63) == 63) sched_yield();
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return STRSIM_OK;
-}
-
-static constexpr uint32_t LANE_LEFT_UNKNOWN = 0xFFFFFFFFu; // the call's first kernel does not report (k_lane_lit, k_lane_pairs)
+static constexpr uint32_t LANE_LEFT_UNKNOWN = 0xFFFFFFFFu; // the call's first kernel has not reported yet
 
 // The slow-row kernels of a call that was enqueued as its lane kernel alone and left rows behind: launched now, behind
 // whatever the stream holds, and waited for.
@@ -220,6 +212,7 @@ static int ctx_run_deferred(strsim_ctx *c, int s)
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_late[0], c->ev_late[1]));
         c->wave_ms += ms;
+        c->wave_launches++;
     }
     return STRSIM_OK;
 }
@@ -228,6 +221,10 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
 {
     int rc = STRSIM_OK;
     c->slot_pending[s] = false;
+    struct Release { // the slot's mask buffer is free again whichever way this function is left
+        strsim_ctx *c; int s;
+        ~Release() { for (int b = 0; b < strsim_ctx::MASKBUFS; ++b) if (c->maskbuf_owner[b] == s) c->maskbuf_owner[b] = -1; }
+    } release{c, s};
     if (!ctx_slot_published(c, s)) { // (cannot happen behind a stream synchronise; strsim_ctx_retire_oldest checks before it gets here)
         c->slot_timed[s] = c->slot_deferred[s] = false;
         set_error("internal: the status block of a completed call was not published (slot %d)", s);
@@ -246,7 +243,8 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
         if (e == hipSuccess && !c->slot_deferred[s]) e = hipEventElapsedTime(&b, c->ev[s][1], c->ev[s][2]);
         if (e == hipSuccess) {
             c->lane_ms += a; c->wave_ms += b;
-            c->lane_launches++; c->wave_launches++;
+            c->lane_launches++;
+            if (!c->slot_deferred[s]) c->wave_launches++; // (a deferred call's slow-row kernels: counted where they are launched)
         } else {
             rc = hip_fail(e, "hipEventElapsedTime");
         }
@@ -278,8 +276,12 @@ static int ctx_drain(strsim_ctx *c)
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
-        if (rc == STRSIM_OK) rc = ctx_retire_slot(c, s);
-        else c->slot_pending[s] = c->slot_timed[s] = c->slot_deferred[s] = false;
+        if (rc == STRSIM_OK) {
+            rc = ctx_retire_slot(c, s);
+        } else {
+            c->slot_pending[s] = c->slot_timed[s] = c->slot_deferred[s] = false;
+            for (int b = 0; b < strsim_ctx::MASKBUFS; ++b) if (c->maskbuf_owner[b] == s) c->maskbuf_owner[b] = -1;
+        }
     }
     return rc;
 }
@@ -324,19 +326,16 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
     strsim_ctx *c = new (std::nothrow) strsim_ctx();
     if (!c) { set_error("out of host memory"); return STRSIM_ERR_OOM; }
     c->device = device;
+    for (int b = 0; b < strsim_ctx::MASKBUFS; ++b) c->maskbuf_owner[b] = -1;
     int rc = ctx_set_device(c);
     if (rc) { delete c; return rc; }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipGetDeviceProperties"); }
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *env = getenv("STRSIM_LANE_WG_PER_CU")) {
-        const int v = atoi(env);
-        if (v >= 1 && v <= 4096) c->lane_wg_per_cu = v;
-    }
     if (const char *env = getenv("STRSIM_STAGE_WG_PER_CU")) {
         const int v = atoi(env);
-        if (v >= 0 && v <= 64) c->stage_wg_per_cu = v;
+        if (v >= 1 && v <= 64) c->stage_wg_per_cu = v;
     }
     {
         const int resident = strsim::wave_lev_resident_per_cu(); // never more than fit: the grid is persistent
@@ -364,7 +363,7 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
     memset(c->status_host, 0, sizeof(DevStatus) * strsim_ctx::RING);
     e = hipHostGetDevicePointer((void **)&c->status_host_dev, c->status_host, 0);
     if (e != hipSuccess) { strsim_ctx_destroy(c); return hip_fail(e, "hipHostGetDevicePointer"); }
-    {   // integer quotients for the epilogues of k_lane_pairs: the host's IEEE division is the device's
+    {   // integer quotients for the epilogues of the one-pair-per-lane kernels: the host's IEEE division is the device's
         static double q[QTAB_N * QTAB_N];
         for (int a = 0; a < QTAB_N; ++a)
             for (int b = 0; b < QTAB_N; ++b) q[a * QTAB_N + b] = b ? (double)a / (double)b : 0.0;
@@ -447,26 +446,24 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     // the ring slot about to be reused must have been retired
     const int slot = c->head;
     if (c->slot_pending[slot]) {
-        rc = strsim_ctx_synchronize(c);
+        // the ring of status slots has wrapped (RING calls in flight without a retire): everything pending is retired here, and
+        // what those calls finished late is kept for the caller's next strsim_ctx_synchronize / strsim_ctx_retire_oldest
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = ctx_drain(c);
+        c->carry_late_rows += c->last_late_rows;
+        c->carry_long_rows += c->last_long_rows;
         if (rc) return rc;
     }
     const uint64_t nchunks = (n + 63) >> 6;
-    // the slot's mask buffer: whoever used it last (MASKBUFS calls ago, or further back) must have been retired -- a call
-    // that is still waiting for its slow-row kernels needs its mask.  Wait for THAT call only (its ticket), not for the
-    // stream: the younger calls keep the GPU busy meanwhile.
-    const int mb = slot % strsim_ctx::MASKBUFS;
-    for (int k = 0; k < strsim_ctx::RING; ++k) {
-        const int s = (c->head + k) % strsim_ctx::RING; // oldest first
-        if (!c->slot_pending[s] || s % strsim_ctx::MASKBUFS != mb) continue;
-        // retire everything up to and including s, in order
-        rc = ctx_wait_published(c, s);
-        if (rc) return rc;
-        for (int j = 0; j <= k; ++j) {
-            const int t = (c->head + j) % strsim_ctx::RING;
-            if (!c->slot_pending[t]) continue;
-            rc = ctx_retire_slot(c, t);
-            if (rc) return rc;
-        }
+    // One launch (the lane kernel alone, the rest at retirement if it turns out to be needed) when the caller has opted in and the
+    // context's last retired call left nothing behind its lane kernel.  Such a call owns a mask buffer until it is retired (there
+    // is always a free one: as many as ring slots).
+    bool defer = !eager && !c->expect_slow && !c->stream_ordered;
+    int mb = strsim_ctx::SHARED_MASKBUF;
+    if (defer) {
+        defer = false;
+        for (int b = 0; b < strsim_ctx::SHARED_MASKBUF; ++b)
+            if (c->maskbuf_owner[b] < 0) { mb = b; defer = true; break; }
     }
     // mask + backup (five-measure call) + the work list of k_lane_utf8 (one u32 per chunk)
     {
@@ -475,7 +472,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         c->slowmask[mb] = static_cast<unsigned long long *>(p);
         if (rc) return rc;
     }
-    // (the status block of the slot is cleared by the first kernel of the call, k_lane_pairs)
+    // (the status block of the slot is cleared by the first kernel of the call)
     if (++c->ticket_seq == 0u) c->ticket_seq = 1u;
     c->slot_ticket[slot] = c->ticket_seq;
     memset(&c->status_host[slot], 0, sizeof(DevStatus)); // (the slot is not pending: nothing on the device writes this block now)
@@ -491,8 +488,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.publish_ticket = 0u;
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask[mb] + 2 * nchunks);
     la.qtab = c->qtab;
-    la.lane_grid = c->num_cu * c->lane_wg_per_cu; // 256-thread workgroups, grid-strided; default = what the VGPR budget admits
-    la.stage_grid = c->stage_wg_per_cu > 0 ? c->num_cu * c->stage_wg_per_cu : 0;
+    la.stage_grid = c->num_cu * c->stage_wg_per_cu;
     la.no_literal_path = getenv("STRSIM_NO_LITERAL_PATH") != nullptr; // (tuning / A-B knob)
     la.long_rows = c->long_rows;
     la.wide_grid = c->num_cu * 3; // resident (LDS)
@@ -520,8 +516,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
             if (!c->ev[slot][i]) HIP_TRY(hipEventCreateWithFlags(&c->ev[slot][i], hipEventDisableSystemFence));
         la.ev_lane0 = c->ev[slot][0]; la.ev_lane1 = c->ev[slot][1]; la.ev_wave1 = c->ev[slot][2];
     }
-    const bool reports = lane_kernel_reports(measure, la); // k_lane_stage: its last workgroup writes lane_left (and a ticket)
-    if (eager && !all && reports && !c->timing) {
+    if (eager && !all && !c->timing) {
         // Small call the caller is going to wait for anyway: launch the one-pair-per-lane kernel alone, let its last
         // workgroup report how many rows it left (host-mapped status word) and wait for it.  Usually that is none --
         // short ASCII strings -- and the call is done after ONE kernel launch instead of five (the three slow-row kernels
@@ -553,8 +548,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         c->head = (slot + 1) % strsim_ctx::RING;
         return STRSIM_OK;
     }
-    if (reports) la.publish_host = c->status_host_dev + slot; // lane_left reaches the host either way: it sets expect_slow
-    const bool defer = reports && !c->expect_slow && !c->stream_ordered;
+    la.publish_host = c->status_host_dev + slot; // lane_left reaches the host either way: it sets expect_slow
     hipError_t e;
     if (defer) {
         la.publish_ticket = c->slot_ticket[slot];
@@ -567,6 +561,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la) + (defer ? 0u : (all ? 21u : 4u));
     c->slot_timed[slot] = c->timing;
     c->slot_deferred[slot] = defer;
+    if (defer) c->maskbuf_owner[mb] = slot;
     c->slot_args[slot] = la;
     c->slot_measure[slot] = measure;
     for (int q = 0; q < STRSIM_NUM_MEASURES; ++q) c->slot_outs[slot][q] = all ? outs[q] : nullptr;
@@ -605,7 +600,11 @@ int strsim_ctx_synchronize(strsim_ctx_t *c)
     int rc = ctx_set_device(c);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return ctx_drain(c);
+    rc = ctx_drain(c);
+    c->last_late_rows += c->carry_late_rows;
+    c->last_long_rows += c->carry_long_rows;
+    c->carry_late_rows = c->carry_long_rows = 0;
+    return rc;
 }
 
 int strsim_internal_scan_workspace(strsim_ctx *c, uint32_t **p)
@@ -622,8 +621,11 @@ int strsim_ctx_retire_oldest(strsim_ctx_t *c)
     if (!c) { set_error("strsim_ctx_retire_oldest: ctx is NULL"); return STRSIM_ERR_ARG; }
     int rc = ctx_set_device(c);
     if (rc) return rc;
-    c->last_long_rows = 0;
-    c->last_late_rows = 0;
+    auto report_carry = [c] { // what calls retired by the library itself finished late goes out with this retirement
+        c->last_long_rows = c->carry_long_rows;
+        c->last_late_rows = c->carry_late_rows;
+        c->carry_late_rows = c->carry_long_rows = 0;
+    };
     for (int k = 0; k < strsim_ctx::RING; ++k) {
         const int s = (c->head + k) % strsim_ctx::RING; // oldest first
         if (!c->slot_pending[s]) continue;
@@ -634,8 +636,10 @@ int strsim_ctx_retire_oldest(strsim_ctx_t *c)
                       "strsim_ctx_stream() behind it, or call strsim_ctx_synchronize())");
             return STRSIM_ERR_ARG;
         }
+        report_carry();
         return ctx_retire_slot(c, s);
     }
+    report_carry();
     return STRSIM_OK; // nothing pending (e.g. a small call that completed inside strsim_pairs_device_small)
 }
 

@@ -57,16 +57,16 @@ struct LaunchArgs {
     double *out; uint64_t n;
     unsigned long long *slowmask; // one 64-bit mask per 64-row chunk
     uint32_t *worklist;           // ceil(n/64) words: the non-empty chunks, compacted by k_lane_utf8
-    const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of k_lane_pairs (device)
-    DevStatus *status;            // cleared by the first kernel of the call (k_lane_pairs)
+    const double *qtab;           // QTAB_N x QTAB_N integer quotients a / b for the epilogues of the one-pair-per-lane kernels (device)
+    DevStatus *status;            // cleared by the first kernel of the call
     uint32_t *sched;              // k_lane_stage: four zeroed words (range counter, finished workgroups, rows left, -); left zeroed by the kernel
     DevStatus *publish_host;      // the last workgroup of k_lane_stage writes lane_left there (host-mapped), else nullptr
     uint32_t publish_ticket;      // != 0: ... and then this ticket: the call consists of that kernel alone
     hipStream_t stream;
-    int lane_grid, wide_grid, wave_grid; // max workgroups for the three kernels
+    int wide_grid, wave_grid;     // resident workgroups of k_lane_wide / k_lane_utf8, waves of k_wave_pairs
     bool no_literal_path;         // A/B runs: a literal call takes k_lane_stage like any other
     bool long_rows;               // the context's last call left many rows behind k_lane_stage: take its instantiation without tables
-    int stage_grid;               // > 0: k_lane_stage (bytes staged through LDS) with this many persistent workgroups
+    int stage_grid;               // k_lane_stage: persistent workgroups at STRSIM_STAGE_WAVES_PER_EU per CU
     int wide_grid_cap;            // k_lane_wide / k_lane_utf8: launch size limit (wide_grid = what is resident)
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
     uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words
@@ -80,9 +80,7 @@ hipError_t launch_slow_only(int measure, const LaunchArgs &a);
 // the same two halves of launch_pairs_all
 hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5]);
 hipError_t launch_slow_all_only(const LaunchArgs &a, double *const outs[5], unsigned long long *mask_backup);
-// does a call of `measure` (STRSIM_NUM_MEASURES = all five) with these arguments start with a kernel whose last workgroup reports
-// lane_left and the ticket (k_lane_stage, k_lane_stage_all, k_lane_lit)?  Not on the k_lane_pairs A/B path.
-bool lane_kernel_reports(int measure, const LaunchArgs &a);
+// (every first kernel of a call -- k_lane_stage, k_lane_stage_all, k_lane_lit + k_publish_lit -- reports lane_left and the ticket)
 // launches the first kernel of such a call takes: 1, or 2 when a literal takes k_lane_lit (+ k_publish_lit behind it)
 int lane_kernel_launches(int measure, const LaunchArgs &a);
 int wave_lev_resident_per_cu();

@@ -5,17 +5,18 @@
 //
 // Kernels, chained through one 64-bit "not finished yet" mask per 64 rows:
 //
-//   k_lane_pairs<M>   ONE PAIR PER LANE, strings <= 32 ASCII bytes (the dominant kernel).  A 256-thread workgroup
-//                     takes 512 consecutive rows, buckets them by DP column count and runs them as 8 rounds of 64
-//                     rows of similar length; each lane pulls its two strings into 2 x 8 VGPRs with unaligned
-//                     16-byte loads, transposes one of them into bit-planes and runs the bit-parallel cores of
-//                     strsim_lane_core.h entirely in registers.  M = 5 is the fused five-output instantiation.
-//   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with 2- or 4-word masks
+//   k_lane_stage<M>   ONE PAIR PER LANE, strings <= 32 ASCII bytes (the dominant kernel; strsim_lane_stage.h).  A persistent
+//                     256-thread workgroup copies the contiguous byte range of a block of up to 512 rows into LDS with
+//                     LDS-DMA, buckets the rows by DP column count and runs them as rounds of 64 rows of similar length:
+//                     each lane picks its two 32-byte windows out of LDS, transposes one into bit-planes and runs the
+//                     bit-parallel cores of strsim_lane_core.h in registers.  k_lane_stage_all: five outputs from one pass.
+//   k_lane_lit<M>     a column against a Utf8 literal (strsim_lane_lit.h): the literal is the wave-uniform text.
+//   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with 2-, 3- or 4-word masks
 //                     (strsim_lane_wide.h), text in an LDS column per lane.
 //   k_lane_utf8<M>    ONE PAIR PER LANE, short non-ASCII strings (<= 32 scalar values, BMP): per-lane UTF-8 decode
 //                     into 16-bit symbols in LDS, then the same cores on symbols (strsim_lane_sym.h).
 //   k_wave_pairs<M>   the rest, up to WAVE_CAP bytes, any UTF-8, taken chunk by chunk from a work list k_lane_utf8 builds.
-//                     Levenshtein: up to 16 pairs per wave in runs of lanes, block-parallel Myers (one 32-row block per
+//                     Levenshtein: up to 16 pairs per wave in runs of lanes, block-parallel Myers (one 64-row block per
 //                     lane, DPP hand-off), match masks from a per-lane LDS table, texts in a global arena; on bytes
 //                     (ASCII) or on 16-bit scalar values (the reference works on `char`s, strsim.rs:133,189,297).
 //                     Other measures: one pair per wave, scalar values in LDS, ballot matching / histograms.
@@ -39,245 +40,17 @@
 
 namespace strsim {
 
-// ------------------------------------------------------------------------------------------------
-// k_lane_pairs: one pair per lane, strings <= 32 ASCII bytes, match masks and DP state in registers.
-//
-// The kernel is VALU-bound (rocprof: VALU ~99 % busy on 32-bit integer ops at 4 cycles per wave64
-// instruction), and every lane of a wave runs as many DP columns as the longest text in the wave.
-// So a 4-wave workgroup takes a block of 512 consecutive rows, buckets them by the number of DP
-// columns they need (8 buckets of 4; LDS counters + a 512-entry permutation) and processes them as 8
-// rounds of 64 rows of similar length -- wave w runs rounds w and 7-w (short + long = balanced).
-// A round runs only as many columns as ITS longest text, rounded up to 4.  The block's offsets are
-// read once, coalesced, and staged in LDS; the strings are fetched per lane (every line of the block
-// is touched by the same CU within a few microseconds: L1/L2 hits); results are staged in LDS and
-// stored coalesced.
-// ------------------------------------------------------------------------------------------------
-#ifndef STRSIM_LANE_BLOCK
-#define STRSIM_LANE_BLOCK 256
-#endif
-constexpr int LANE_BLOCK = STRSIM_LANE_BLOCK;    // threads per workgroup
-constexpr int LANE_WAVES = LANE_BLOCK / 64;      // 4
-#ifndef STRSIM_LANE_RPW
-#define STRSIM_LANE_RPW 2
-#endif
-constexpr int LANE_RPW = STRSIM_LANE_RPW;        // rounds per wave and block (even; 4 = 1 024-row blocks: measured no gain)
-constexpr int LANE_ROUNDS = LANE_RPW * LANE_WAVES; // rounds of 64 rows per block (8)
-constexpr int LANE_ROWS = 64 * LANE_ROUNDS;      // 512 rows per block
-constexpr int LANE_RPT = LANE_ROWS / LANE_BLOCK; // rows per thread in the coalesced phases (2)
-
 constexpr int ALL_MEASURES = 5; // MEASURE value of the fused five-output instantiation
 
 struct OutPtrs {
     double *p[5]; // indexed by Measure; single-measure kernels use p[0]
 };
 
-// Register budget of k_lane_pairs.  With five-, six- and seven-plane instantiations in one kernel the allocation was 86
-// (Levenshtein) to 114 (Jaro) VGPRs although each instantiation alone needs 52-57; dropping the six-plane one (it
-// runs as seven) brings the kernel to 63-64 VGPRs = 8 waves per SIMD with at most 9 spilled dwords: cfg2 Levenshtein
-// 2.02 -> 1.95 ms, Jaro 2.77 -> 2.69, Jaccard 1.78 -> 1.76 (6, 7 and 8 waves asked for measure the same).
-#ifndef STRSIM_LANE_WAVES_PER_EU
-#define STRSIM_LANE_WAVES_PER_EU 8
-#endif
-#if STRSIM_LANE_WAVES_PER_EU
-#define LANE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(STRSIM_LANE_WAVES_PER_EU)))
-#else
-#define LANE_OCCUPANCY
-#endif
-
-template <int MEASURE>
-__device__ __forceinline__ void lane_pairs_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA,
-                                                uint64_t rowsA, const uint32_t *__restrict__ offB,
-                                                const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                                                unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
-                                                const double *__restrict__ qtab)
-{
-    constexpr int NOUT = MEASURE == ALL_MEASURES ? 5 : 1;
-#ifndef STRSIM_LANE_BUCKET_SHIFT
-#define STRSIM_LANE_BUCKET_SHIFT 2
-#endif
-    constexpr int BSH = STRSIM_LANE_BUCKET_SHIFT;        // buckets of 2^BSH column counts (4; buckets of 2 measured 1 % slower)
-    constexpr int NBK = (32 >> BSH) + 1;                 // + one for the rows this kernel skips (sorted last)
-    __shared__ uint32_t s_cnt[2][NBK];                  // bucket counters (double-buffered by block parity)
-    __shared__ unsigned long long s_late[2][LANE_ROUNDS]; // rows found non-ASCII after their bytes were loaded
-    __shared__ uint16_t s_perm[LANE_ROWS];
-    __shared__ uint32_t s_a0[LANE_ROWS];
-    __shared__ uint32_t s_b0[LANE_ROWS];
-    __shared__ uint32_t s_len[LANE_ROWS];               // la | lb << 16, or ~0 for rows this kernel skips
-    __shared__ double s_out[NOUT][LANE_ROWS];
-    constexpr bool HAS_LEV = MEASURE == LEVENSHTEIN || MEASURE == ALL_MEASURES;
-    __shared__ double s_levtab[HAS_LEV ? 33 * 33 : 1]; // (in global memory instead, like qtab: measured 2-4 % slower)
-
-    // Levenshtein distance and the multiset intersection do not depend on the argument order
-    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = lane_id();
-    const uint32_t wv = tid >> 6;
-    // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
-    if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
-    if (HAS_LEV) {
-        // 1.0 - dist/den for every (dist, den) a <= 32-byte pair can produce: same IEEE division as the
-        // epilogue, done once per workgroup instead of once per pair
-        for (uint32_t i = tid; i < 33u * 33u; i += LANE_BLOCK) {
-            const uint32_t d = i / 33u, m = i % 33u;
-            s_levtab[i] = m ? epilogue_levenshtein(d, m, m) : 0.0;
-        }
-    }
-    const uint32_t totalA = offA[rowsA];
-    const uint32_t totalB = offB[rowsB];
-    const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
-    const uint64_t nblocks = (n + (LANE_ROWS - 1)) / LANE_ROWS;
-    uint32_t par = 0;
-    __builtin_amdgcn_s_setprio(1);
-
-    for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, par ^= 1u) {
-        const uint64_t row0 = blk * LANE_ROWS;
-        if (tid < (uint32_t)NBK) s_cnt[par][tid] = 0u;
-        if (tid < (uint32_t)LANE_ROUNDS) s_late[par][tid] = 0ull;
-        lds_barrier();
-        // ---- phase 1 (coalesced): offsets -> lengths -> bucket + rank; stage offsets in LDS ---------
-        uint32_t key[LANE_RPT], rank[LANE_RPT];
-        unsigned long long skip[LANE_RPT]; // per 64-row chunk (q * 4 + wv): rows this kernel will not write
-#pragma unroll
-        for (int q = 0; q < LANE_RPT; ++q) {
-            const uint32_t i = q * LANE_BLOCK + tid;
-            const uint64_t row = row0 + i;
-            const bool valid = row < n;
-            uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-            if (valid) {
-                const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-                a0 = offA[ra]; a1 = offA[ra + 1];
-                b0 = offB[rb]; b1 = offB[rb + 1];
-            }
-            const uint32_t la8 = a1 - a0, lb8 = b1 - b0;
-            const bool mine = valid && la8 <= 32u && lb8 <= 32u;
-            skip[q] = __ballot(!mine);
-            // bucket by the number of DP columns the pair will run (SYMMETRIC measures walk the shorter string)
-            const uint32_t steps = SYMMETRIC ? (la8 < lb8 ? la8 : lb8) : la8;
-            key[q] = mine ? (((steps ? steps : 1u) - 1u) >> BSH) : (uint32_t)(NBK - 1);
-            rank[q] = atomicAdd(&s_cnt[par][key[q]], 1u);
-            s_a0[i] = a0;
-            s_b0[i] = b0;
-            s_len[i] = mine ? (la8 | (lb8 << 16)) : 0xFFFFFFFFu;
-        }
-        lds_barrier();
-        {
-            uint32_t c[NBK];
-#pragma unroll
-            for (int k = 0; k < NBK; ++k) c[k] = s_cnt[par][k];
-#pragma unroll
-            for (int q = 0; q < LANE_RPT; ++q) {
-                uint32_t base = 0;
-#pragma unroll
-                for (int k = 0; k < NBK - 1; ++k) base += ((uint32_t)k < key[q]) ? c[k] : 0u;
-                s_perm[base + rank[q]] = (uint16_t)(q * LANE_BLOCK + tid);
-            }
-        }
-        lds_barrier();
-
-        // ---- phase 2: wave w runs rounds w and 7-w (64 rows of similar length each) -----------------
-#pragma unroll 1
-        for (int rr = 0; rr < LANE_RPW; ++rr) {
-            // rounds come sorted by length: a wave takes one from each end of every group of 2 * LANE_WAVES rounds
-            const uint32_t grp = (uint32_t)(rr >> 1) * (2u * LANE_WAVES);
-            const uint32_t r = grp + ((rr & 1) ? (uint32_t)(2 * LANE_WAVES - 1) - wv : wv);
-            const uint32_t idx = s_perm[r * 64u + lane];
-            const uint32_t len = s_len[idx];
-            bool fast = len != 0xFFFFFFFFu;
-            uint32_t la8 = fast ? (len & 0xFFFFu) : 0u, lb8 = fast ? (len >> 16) : 0u;
-            // symmetric measures walk the shorter string: pick the roles BEFORE loading (no register swap);
-            // rows this kernel skips read a harmless window at offset 0
-            const bool swap = SYMMETRIC && la8 > lb8;
-            const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
-            const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
-            uint32_t t0 = swap ? s_b0[idx] : s_a0[idx], p0 = swap ? s_a0[idx] : s_b0[idx];
-            if (!fast) { t0 = 0u; p0 = 0u; }
-            if (swap) { const uint32_t t = la8; la8 = lb8; lb8 = t; }
-            // (fetching the second round's windows during the first round was tried: 102 VGPRs, 4 waves per SIMD, -11 %)
-            uint32_t wa[8], wb[8];
-            load_window32(vT, t0, tT, wa);
-            load_window32(vP, p0, tP, wb);
-            // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any
-            // high bit sends the row to the code-point kernel; the varying low bits decide how many bit-planes
-            // the match masks need
-            uint32_t any;
-            const uint32_t vary = window_vary(wa, wb, any);
-            if (fast && (any & 0x80u)) {
-                fast = false;
-                atomicOr(&s_late[par][idx >> 6], 1ull << (idx & 63u));
-            }
-            if (__ballot(fast) == 0ull) continue;
-            const uint32_t la = fast ? la8 : 0u, lb = fast ? lb8 : 0u;
-            const uint32_t tmax = wave_max_rounded(la);
-            // The memory phases of a block (offset loads, window loads, stores) run at a higher wave priority than the
-            // column loops: a wave that only has loads to issue gets them out ahead of the waves that are computing, and
-            // comes back with its data sooner (cfg2: 1.93 -> 1.89 ms; the opposite assignment costs 3 %).
-            __builtin_amdgcn_s_setprio(0);
-            const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
-            const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
-            if (MEASURE == ALL_MEASURES) {
-                double res[5];
-                if (need7 || need6) lane_all_results<7>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
-                else lane_all_results<5>(wa, la, wb, lb, tmax, s_levtab, res, qtab);
-                if (fast) {
-#pragma unroll
-                    for (int q = 0; q < NOUT; ++q) s_out[q][idx] = res[q];
-                }
-            } else {
-                constexpr int M1 = MEASURE == ALL_MEASURES ? 0 : MEASURE;
-                double res;
-                // Two instantiations, not three: with a six-plane variant beside these the register allocation of the whole
-                // kernel grew from 64 to 80+ VGPRs (each variant alone needs 52-57), i.e. from 8 to 6 waves per SIMD
-                if (need7 || need6) res = lane_pair_result<M1, 7>(wa, la, wb, lb, tmax, s_levtab, qtab);
-                else res = lane_pair_result<M1, 5>(wa, la, wb, lb, tmax, s_levtab, qtab);
-                if (fast) s_out[0][idx] = res;
-            }
-            __builtin_amdgcn_s_setprio(1);
-        }
-        lds_barrier();
-        // ---- phase 3 (coalesced): store the finished rows, one mask word per 64-row chunk ------------
-#pragma unroll
-        for (int q = 0; q < LANE_RPT; ++q) {
-            const uint32_t i = q * LANE_BLOCK + tid;
-            const uint64_t row = row0 + i;
-            const unsigned long long sk = skip[q] | s_late[par][i >> 6];
-            if (!((sk >> lane) & 1ull)) {
-#pragma unroll
-                for (int o = 0; o < NOUT; ++o) outs.p[o][row] = s_out[o][i];
-            }
-            if (lane == 0u && row < n)
-                slowmask[row >> 6] = sk & (n - row >= 64u ? ~0ull : ((1ull << (n - row)) - 1ull));
-        }
-    }
-}
-
-template <int MEASURE>
-__global__ __launch_bounds__(LANE_BLOCK) LANE_OCCUPANCY void k_lane_pairs(const uint32_t *__restrict__ offA,
-                                                                          const uint8_t *__restrict__ valA, uint64_t rowsA,
-                                                                          const uint32_t *__restrict__ offB,
-                                                                          const uint8_t *__restrict__ valB, uint64_t rowsB,
-                                                                          OutPtrs outs, uint64_t n,
-                                                                          unsigned long long *__restrict__ slowmask,
-                                                                          DevStatus *__restrict__ status,
-                                                                          const double *__restrict__ qtab)
-{
-    lane_pairs_body<MEASURE>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
-}
-
-// The fused five-output instantiation needs more registers: asked for 5 waves per SIMD it fits 126 VGPRs = 4 waves
-// (132 = 3 waves when asked for 6, or for nothing).
-__global__ __launch_bounds__(LANE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
-k_lane_pairs_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
-                 const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                 unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab)
-{
-    lane_pairs_body<ALL_MEASURES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab);
-}
-
 #include "strsim_lane_stage.h"
 #include "strsim_lane_lit.h"
 
 // ------------------------------------------------------------------------------------------------
-// k_lane_wide: one pair per lane for the rows k_lane_pairs left behind whose strings are 33..128 ASCII
+// k_lane_wide: one pair per lane for the rows k_lane_stage left behind whose strings are 33..128 ASCII
 // bytes: W = 2 (<= 64), 3 (<= 96) or 4 (<= 128) word masks (strsim_lane_wide.h).  A workgroup takes a span of
 // WIDE_SPAN mask words (2048 rows), collects the flagged rows of each width class into LDS lists and runs
 // them 64 at a time; finished rows are cleared from the mask, the rest (non-ASCII, longer, empty side)
@@ -393,8 +166,8 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const LdsSa sa{STRSIM_LDS_ADDR(txt_col)};
     // Jaro's second pass walks b: as far as the round's longest one reaches
     const uint32_t nb4 = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? (wave_max_u8(fast ? lb : 0u) + 3u) >> 2 : 0u;
-    // two instantiations per width (a six-plane one only inflated the kernel's register allocation, cf. k_lane_pairs)
-    __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
+    // two instantiations per width (a six-plane one only inflated the kernel's register allocation)
+    __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue
     if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
     else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
     __builtin_amdgcn_s_setprio(1);
@@ -709,7 +482,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                 const bool need16 = __ballot(ok && (vary >> 11)) != 0ull;
                 const bool need11 = __ballot(ok && (vary >> 8)) != 0ull;
                 double res;
-                __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue (cf. k_lane_pairs)
+                __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue
                 if (need16) res = lane_sym_result<MEASURE, 16>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
                 else if (need11) res = lane_sym_result<MEASURE, 11>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
                 else res = lane_sym_result<MEASURE, 8>(LdsSym{tcol}, lt, steps, LdsSym{pcol}, lp);
@@ -2198,13 +1971,6 @@ static uint64_t stage_launch_size(uint64_t nsb, uint64_t resident, uint64_t cus)
 template <int M>
 static void launch_lane_t(const LaunchArgs &a)
 {
-    const uint64_t nchunks = (a.n + 63u) >> 6;
-    const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
-    const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
-    // waves per CU: Levenshtein by its 8 KB table; Jaro by its 12.4 KB of LDS (12); Jaccard / Dice 16 (a.wave_grid)
-    const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
-                        : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 4u : (uint64_t)a.wave_grid;
-    const uint64_t g2 = nchunks < wg ? nchunks : wg;
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
@@ -2212,7 +1978,7 @@ static void launch_lane_t(const LaunchArgs &a)
     // for the symmetric measures, only a literal a for Jaro / Jaro-Winkler (they walk a)
     const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
     const bool lit_path = (M == JARO || M == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
-    if (a.stage_grid > 0 && lit_path && !a.no_literal_path) {
+    if (lit_path && !a.no_literal_path) {
         const bool litA = lit_a;
         const uint64_t nlb = (a.n + (LIT_ROWS - 1)) / LIT_ROWS;
         const uint64_t want = (uint64_t)a.stage_grid * 3u; // ~15 workgroups per CU in the launch, 5 resident
@@ -2221,7 +1987,7 @@ static void launch_lane_t(const LaunchArgs &a)
                            litA ? a.valB : a.valA, litA ? a.offA : a.offB, litA ? a.valA : a.valB, a.out, a.n, a.slowmask,
                            a.status, a.qtab, a.sched);
         if (a.publish_host) hipLaunchKernelGGL(k_publish_lit, dim3(1), dim3(64), 0, a.stream, a.sched, a.publish_host, a.publish_ticket);
-    } else if (a.stage_grid > 0) {
+    } else {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; an instantiation that runs fewer gets its share)
@@ -2237,9 +2003,6 @@ static void launch_lane_t(const LaunchArgs &a)
         } else {
             go(std::false_type{});
         }
-    } else {
-        hipLaunchKernelGGL((k_lane_pairs<M>), dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
 }
@@ -2320,12 +2083,10 @@ static void launch_slow_kernels(const LaunchArgs &a, double *out)
 hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5])
 {
     if (a.n == 0) return hipSuccess;
-    const uint64_t nblk = (a.n + (LANE_ROWS - 1)) / LANE_ROWS;
-    const uint64_t g1 = nblk < (uint64_t)a.lane_grid ? nblk : (uint64_t)a.lane_grid;
     OutPtrs op{};
     for (int q = 0; q < 5; ++q) op.p[q] = outs[q];
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
-    if (a.stage_grid > 0) {
+    {
         // one staged pass, five outputs (strsim_lane_stage.h, MEASURE = ALL_MEASURES)
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         const uint64_t cap = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>()>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU; // resident workgroups
@@ -2333,9 +2094,6 @@ hipError_t launch_lane_all_only(const LaunchArgs &a, double *const outs[5])
         hipLaunchKernelGGL(k_lane_stage_all, dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA,
                            a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host,
                            a.publish_ticket);
-    } else {
-        hipLaunchKernelGGL(k_lane_pairs_all, dim3((unsigned)g1), dim3(LANE_BLOCK), 0, a.stream, a.offA, a.valA,
-                           a.rowsA, a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab);
     }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
     return hipGetLastError();
@@ -2383,17 +2141,10 @@ int wave_lev_resident_per_cu()
 
 int lane_kernel_launches(int measure, const LaunchArgs &a)
 {
-    if (a.stage_grid <= 0 || measure == 5) return 1;
+    if (measure == 5) return 1;
     const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
     const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
     return (lit_path && !a.no_literal_path) ? 2 : 1; // k_lane_lit + k_publish_lit
-}
-
-bool lane_kernel_reports(int measure, const LaunchArgs &a)
-{
-    if (a.stage_grid <= 0) return false;
-    (void)measure;
-    return true; // k_lane_stage / k_lane_stage_all report themselves, k_lane_lit through k_publish_lit (only the k_lane_pairs A/B path does not)
 }
 
 hipError_t launch_lane_only(int measure, const LaunchArgs &a)
@@ -2462,8 +2213,8 @@ hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, ui
 } // namespace strsim
 
 
-#ifdef STRSIM_STAGE_STAMPS
-// diagnostic build only: copies the per-wave phase cycle sums of the last k_lane_stage launch to the host
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
+// lab build only: copies the per-wave phase cycle sums of the last k_lane_stage launch to the host
 extern "C" __attribute__((visibility("default"))) int strsim_debug_stage_stamps(unsigned long long *dst, size_t waves)
 {
     if (waves > 16384) waves = 16384;

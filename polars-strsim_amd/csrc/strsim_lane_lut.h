@@ -52,10 +52,7 @@ struct LutIndex {
 STRSIM_HD LutIndex lut_index(const EqLut &t, uint32_t w)
 {
     LutIndex x;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(STRSIM_LUT_PACKED)
-    x.l = (w & 0x07070707u) + t.krep;                                // K need not be a multiple of 16: add, byte by byte
-    x.m = ((w >> 3) & 0x03030303u) + (t.krep + 0x08080808u);
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     x.l = bitop3<0xEA>(w, 0x07070707u, t.krep);                      // (w & 7s) | K
     x.m = bitop3<0xEA>(w >> 3, 0x03030303u, t.krep | 0x08080808u);  // ((w >> 3) & 3s) | (K + 8)
 #else
@@ -170,103 +167,6 @@ STRSIM_HD uint32_t lev_myers32_lut(const EqLut &t, const uint32_t (&wt)[8], uint
                 const uint32_t X = bitop3<0xBE>(bitop3<0x80>(l, m, Pv) + Pv, Pv, Mv); // (((Eq & Pv) + Pv) ^ Pv) | Mv
                 D0 = bitop3<0xF8>(X, l, m);                                           // | Eq
             }
-            const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
-            const uint32_t nX = twice(nHP);                                 // ~((HP << 1) | 1)
-            const uint32_t HN2 = twice(D0 & Pv);                            // HN << 1
-            Pv = bitop3<0xF2>(HN2, D0, nX);                                 // (HN << 1) | ~(D0 | X)
-            Mv = bitop3<0x50>(D0, D0, nX);                                  // D0 & X
-        };
-        if ((uint32_t)(CPT * (g + 1)) >= tmin) {                           // (uniform) some lane's text may end in this group
-#pragma unroll
-            for (int jj = 0; jj < CPT; ++jj)
-                if ((uint32_t)(CPT * g + jj) < lt) column(jj);
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < CPT; ++jj) column(jj);
-        }
-        return true;
-    });
-    const uint32_t rows = low_ones(lp);
-    return lt + popc32(Pv & rows) - popc32(Mv & rows);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The SMALL table: only M (planes 3..4, four entries, 1 KB per wave at a 1 KB boundary) lives in LDS; planes 0..2 (and 5..)
-// are applied with bit fills on top of the entry read: Eq(c) = M[(c >> 3) & 3] & AND_{k in 0,1,2,5..} ~(P_k ^ m_k) -- the
-// entry is the start value of the chain, so it costs one v_perm_b32 and one ds_read_b32 in place of two bit fills and two
-// three-input ops (50 instead of 59 cycles of SIMD time per Levenshtein column).  For the instantiations of k_lane_stage that
-// are issue-bound at five workgroups per CU: 4 KB of LDS per workgroup keeps them there (28 + 4 KB), the full tables would not.
-// ---------------------------------------------------------------------------------------------
-constexpr int MLUT_ENTRIES = 4;
-constexpr int MLUT_WAVE_BYTES = MLUT_ENTRIES * 256;
-
-STRSIM_HD uint32_t mlut_index(const EqLut &t, uint32_t w)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return bitop3<0xEA>(w >> 3, 0x03030303u, t.krep); // ((w >> 3) & 3s) | K, K a multiple of 4
-#else
-    (void)t;
-    return (w >> 3) & 0x03030303u;
-#endif
-}
-
-template <int NP>
-STRSIM_HD void mlut_build(EqLut &t, const uint32_t (&P)[NP], uint32_t valid)
-{
-    static_assert(NP >= 5, "the table covers planes 3..4");
-    uint32_t e[MLUT_ENTRIES];
-    e[0] = bitop3<0x02>(P[3], P[4], valid);
-    e[1] = bitop3<0x20>(P[3], P[4], valid);
-    e[2] = bitop3<0x08>(P[3], P[4], valid);
-    e[3] = bitop3<0x80>(P[3], P[4], valid);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t base = t.lane4 + ((t.krep & 0xFFu) << 8);
-#pragma unroll
-    for (int q = 0; q < MLUT_ENTRIES; ++q) lut_lds_write(base + 256u * (uint32_t)q, e[q]);
-#else
-#pragma unroll
-    for (int q = 0; q < MLUT_ENTRIES; ++q) t.tab[q] = e[q];
-#endif
-}
-
-// match mask of character `byte` of text dword w: the table entry m, then the planes the table does not cover
-template <int NP>
-STRSIM_HD uint32_t mlut_eq(const uint32_t (&P)[NP], uint32_t m, uint32_t w, int byte)
-{
-    uint32_t acc = m;
-#pragma unroll
-    for (int k = 0; k < NP; ++k)
-        if (k < 3 || k >= 5) acc = bitop3<0x90>(acc, P[k], bit_fill(w, 8 * byte + k));
-    return acc;
-}
-
-// lev_myers32_snap with the small table (same contract as lev_myers32_lut; `t` holds mlut_build(P, ~0))
-template <int NP>
-STRSIM_HD uint32_t lev_myers32_mlut(const EqLut &t, const uint32_t (&wt)[8], uint32_t lt, uint32_t tmin, uint32_t tmax,
-                                    const uint32_t (&P)[NP], uint32_t lp)
-{
-    constexpr int CPT = COLS_PER_TEST, NG = 32 / COLS_PER_TEST;
-    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
-    uint32_t M[NG + LUT_AHEAD][CPT];
-    uint32_t ix = mlut_index(t, wt[0]);
-    auto fetch = [&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-#pragma unroll
-        for (int jj = 0; jj < CPT; ++jj) {
-            const int j = CPT * g + jj;
-            if ((j & 3) == 0 && j != 0) ix = mlut_index(t, wt[(j >> 2) & 7]);
-            M[g][jj] = lut_read(t, ix, j & 3);
-        }
-    };
-    unrolled_until<0, LUT_AHEAD>([&](auto gc) { fetch(gc); return true; });
-    unrolled_until<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if ((uint32_t)(CPT * g) >= tmax) return false;
-        if constexpr (g + LUT_AHEAD < NG) fetch(std::integral_constant<int, g + LUT_AHEAD>{});
-        auto column = [&](int jj) {
-            const int j = CPT * g + jj;
-            const uint32_t Eq = mlut_eq<NP>(P, M[g][jj], wt[j >> 2], j & 3);
-            const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
             const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
             const uint32_t nX = twice(nHP);                                 // ~((HP << 1) | 1)
             const uint32_t HN2 = twice(D0 & Pv);                            // HN << 1

@@ -1,14 +1,13 @@
 // strsim_lane_stage.h -- k_lane_stage<M>: the one-pair-per-lane kernel for strings of <= 32 ASCII bytes with the
 // string bytes STAGED THROUGH LDS.  Included by strsim_kernels.hip inside namespace strsim, after its helpers.
 //
-// Same per-pair arithmetic as k_lane_pairs (strsim_lane_core.h; reference strsim.rs:125-162, :180-245, :257-272,
-// :286-308, :322-345).  What changes is how the bytes reach the lanes.  k_lane_pairs has every lane pull its two
-// 32-byte windows with unaligned 16-byte global loads in length-sorted (= scattered) order: 4 load instructions of 64
-// different cache-line pairs each per 64 pairs, which keeps the CU's texture-address unit busy ~600 cycles per 64
-// pairs -- the unit, not the VALU and not HBM, is what bounds that kernel (TA_BUSY ~ kernel time).  Here
+// Per-pair arithmetic: strsim_lane_core.h (reference strsim.rs:125-162, :180-245, :257-272, :286-308, :322-345).
+// How the bytes reach the lanes: a lane pulling its two 32-byte windows with unaligned 16-byte global loads in length-sorted
+// (= scattered) order costs 4 load instructions of 64 different cache-line pairs each per 64 pairs, which keeps the CU's
+// texture-address unit busy ~600 cycles per 64 pairs (round 1's kernel was bound by that unit).  Here
 // a workgroup copies the CONTIGUOUS byte range of its block of rows from both value buffers into LDS with coalesced
 // 16-byte-per-lane LDS-DMA loads (global_load_lds_dwordx4: every 128-byte line crosses the address unit once and
-// never touches a VGPR) and the lanes then pick their windows out of LDS with two unaligned ds_read_b128 each.
+// never touches a VGPR) and the lanes then pick their windows out of LDS as nine aligned dwords + eight v_alignbyte.
 //
 //   per block of STAGE_ROWS consecutive rows (persistent 256-thread workgroup, grid-stride over blocks):
 //     A  bytes DMA(j)      both columns' byte ranges of block j -> s_bytes (in flight during B and C)
@@ -24,7 +23,7 @@
 //   Three LDS-only barriers per block.  Blocks are cut to fit: a workgroup owns a contiguous range of 64-row chunks and
 //   takes as many of the next chunks (at most STAGE_ROWS / 64) as have their bytes inside the staging area, so data
 //   with longer rows simply runs in smaller blocks.  Rows longer than 32 bytes, non-ASCII rows and rows of a single
-//   chunk that alone overflows the staging area stay in the mask for the later kernels, as with k_lane_pairs.
+//   chunk that alone overflows the staging area stay in the mask for the later kernels.
 #pragma once
 
 #ifndef STRSIM_STAGE_ROWS
@@ -55,34 +54,14 @@
 #ifndef STRSIM_STAGE_RANGE_MIN_BLOCKS
 #define STRSIM_STAGE_RANGE_MIN_BLOCKS 2 // ... and at least this many blocks (1: a 3 M-row call 132 us instead of 102, cfg2 +2 %: the counter is one contended address)
 #endif
-#ifndef STRSIM_STAGE_ALIAS
-#define STRSIM_STAGE_ALIAS 0 // experiment (with tables): every window of the block is fetched first, then -- behind one more barrier --
-#endif                       // the tables live in the staging area (no LDS of their own: room for larger blocks at 4 workgroups per CU)
-#ifndef STRSIM_STAGE_DIVIDE
-#define STRSIM_STAGE_DIVIDE 0 // 1: Levenshtein's 1 - dist / den divides in the store phase instead of reading the quotient table
-#endif
-#ifndef STRSIM_STAGE_PRIO
-#define STRSIM_STAGE_PRIO 1
-#endif
-#ifndef STRSIM_STAGE_PRIO_WINDOWS
-#define STRSIM_STAGE_PRIO_WINDOWS 1
-#endif
-#ifndef STRSIM_STAGE_PRIO_PLANES
-#define STRSIM_STAGE_PRIO_PLANES 0
-#endif
-#ifndef STRSIM_STAGE_STORE_FIRST
-#define STRSIM_STAGE_STORE_FIRST 1
-#endif
 
-#ifdef STRSIM_STAGE_STAMPS
-// diagnostic build only (never in the product library): per-wave cycle sums of the phases of k_lane_stage, read back with
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
+// lab build only (make EXTRA="-DSTRSIM_LAB -DSTRSIM_STAGE_STAMPS"; never in the product library): per-wave cycle sums of the phases of k_lane_stage, read back with
 // strsim_debug_stage_stamps().  [0] block cut + bytes DMA issue [1] store [2] sortA [3] barrier [4] sortB [5] DMA wait +
 // barrier [6] offsets DMA issue [7] rounds: descriptor + windows [8] rounds: cores [9] barrier G [10] all [11] all (100 MHz)
 __device__ unsigned long long g_stage_stamps[16384][16]; // [12], [13]: s_memrealtime at the wave's start and end
 #define STAGE_STAMP(cat) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                               __builtin_amdgcn_sched_barrier(0); st_acc[cat] += t_ - st_last; st_last = t_; } while (0)
-#elif defined(STRSIM_STAGE_FENCES)
-#define STAGE_STAMP(cat) do { __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAGE_STAMP(cat) do { } while (0)
 #endif
@@ -101,11 +80,6 @@ constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and blo
 // Jaro 41 -> 45.6 G pairs/s on cfg2's lengths.  Levenshtein, Jaccard and Dice are issue-bound at 5 workgroups per CU and
 // latency-bound at 4: 28 % fewer vector instructions bought nothing there.
 template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_LUT >> MEASURE) & 1) != 0; } // (5: five outputs)
-// ... and which use the SMALL table (planes 3..4 only, 4 KB of LDS per workgroup: still five workgroups per CU)
-#ifndef STRSIM_STAGE_MLUT
-#define STRSIM_STAGE_MLUT 0x00 // none: measured on cfg2, Levenshtein 1.42 -> 1.53 ms (the extra LDS reads cost more than the bit fills they replace)
-#endif
-template <int MEASURE> constexpr bool stage_uses_mlut() { return !stage_uses_lut<MEASURE>() && ((STRSIM_STAGE_MLUT >> MEASURE) & 1) != 0; }
 
 // staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
 template <bool TABLES> struct StageGeom {
@@ -159,16 +133,11 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // when both sides are columns.
 constexpr uint32_t STAGE_DEAD = 1u << 31;
 
-#ifndef STRSIM_STAGE_ALIGNED_WINDOWS
-#define STRSIM_STAGE_ALIGNED_WINDOWS 1 // cfg2: 1.587 ms against 1.636 ms with 0 (same box, same run)
-#endif
-// 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7].
-//   0: two ds_read_b128 at the byte address.  gfx950 serves a wide LDS read that is not naturally aligned one lane at a time
-//      (129 LDS cycles per 64-lane window, whatever the width: bench_support/micro/lds_window.hip) but it costs no VALU;
-//   1: nine dwords from the dword-aligned address below (ds_read2_b32, 56 LDS cycles) + eight v_alignbyte_b32.
+// 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7]: nine dwords from the dword-aligned address below (56 LDS
+// cycles per 64 lanes) + eight v_alignbyte_b32.  (gfx950 serves a wide LDS read that is not naturally aligned one lane at a time:
+// two ds_read_b128 at the byte address cost 129 LDS cycles, bench_support/micro/lds_window.hip; cfg2 1.636 vs 1.587 ms.)
 __device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, uint32_t (&w)[8])
 {
-#if STRSIM_STAGE_ALIGNED_WINDOWS
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     const uint8_t *q = base + (at & ~3u);
     const u32x4_a4 lo = *reinterpret_cast<const u32x4_a4 *>(q);
@@ -179,13 +148,6 @@ __device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, u
     w[2] = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh); w[3] = __builtin_amdgcn_alignbyte(hi.x, lo.w, sh);
     w[4] = __builtin_amdgcn_alignbyte(hi.y, hi.x, sh); w[5] = __builtin_amdgcn_alignbyte(hi.z, hi.y, sh);
     w[6] = __builtin_amdgcn_alignbyte(hi.w, hi.z, sh); w[7] = __builtin_amdgcn_alignbyte(top, hi.w, sh);
-#else
-    const uint8_t *p = base + at;
-    const u32x4_unaligned lo = *reinterpret_cast<const u32x4_unaligned *>(p);
-    const u32x4_unaligned hi = *reinterpret_cast<const u32x4_unaligned *>(p + 16);
-    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-    w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
-#endif
 }
 
 // inclusive prefix sum over lanes 0..31 (and, independently, 32..63) with five DPP adds: shifts by 1, 2, 4, 8 inside the
@@ -201,23 +163,17 @@ __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
 }
 
 // Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
-template <int NP, int USE_LUT> // 0: bit fills, 1: the full tables, 2: the small table
+template <int NP, bool USE_LUT> // match masks from bit fills / from the tables
 __device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
                                                    uint32_t lb, uint32_t tmin, uint32_t tmax)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
     EqLut t = lut;
-    if (USE_LUT == 1) lut_build<NP>(t, P, 0xFFFFFFFFu);
-    if (USE_LUT == 2) mlut_build<NP>(t, P, 0xFFFFFFFFu);
-#if STRSIM_STAGE_PRIO_PLANES
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    if (USE_LUT) lut_build<NP>(t, P, 0xFFFFFFFFu);
     const bool live = la != 0u && lb != 0u;
     const uint32_t la1 = live ? la : 1u, lb1 = live ? lb : 1u;
-    const uint32_t dist = USE_LUT == 1   ? lev_myers32_lut<NP>(t, wa, la1, tmin, tmax, P, lb1)
-                          : USE_LUT == 2 ? lev_myers32_mlut<NP>(t, wa, la1, tmin, tmax, P, lb1)
-                                         : lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
+    const uint32_t dist = USE_LUT ? lev_myers32_lut<NP>(t, wa, la1, tmin, tmax, P, lb1) : lev_myers32_snap<NP>(wa, la1, tmin, tmax, P, lb1);
     uint32_t code = dist * (uint32_t)QTAB_N + (la1 > lb1 ? la1 : lb1);
     // both empty: 1.0 = 1 - 0/1; one side empty: 0.0 = 1 - 1/1   (strsim.rs:128, :160)
     if (!live) code = (la == 0u && lb == 0u) ? 1u : (uint32_t)QTAB_N + 1u;
@@ -316,7 +272,6 @@ template <int MEASURE, bool LUT>
 __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (&wt)[8], const uint32_t (&wp)[8], uint32_t meta,
                                               uint32_t last, uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
-    constexpr int LUTMODE = LUT ? 1 : (stage_uses_mlut<MEASURE>() ? 2 : 0);
     bool fast = (meta & STAGE_DEAD) == 0u;
     const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
     // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any high bit leaves
@@ -337,21 +292,8 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
     const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
     if (MEASURE == LEVENSHTEIN) {
         uint32_t code;
-#if defined(STRSIM_EXP_NOCORE)   // diagnostic builds only: everything but the cores / the cores twice
-        code = (la + tmin + tmax + (wide ? 1u : 0u)) * (uint32_t)QTAB_N + lb;
-#else
-        if (wide) code = stage_lev_code<7, LUTMODE>(lut, wt, la, wp, lb, tmin, tmax);
-        else code = stage_lev_code<5, LUTMODE>(lut, wt, la, wp, lb, tmin, tmax);
-#if defined(STRSIM_EXP_CORE2X)
-        {
-            uint32_t wt2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) wt2[q] = wt[q] ^ (code >> 31);
-            if (wide) code = stage_lev_code<7, LUTMODE>(lut, wt2, la, wp, lb, tmin, tmax);
-            else code = stage_lev_code<5, LUTMODE>(lut, wt2, la, wp, lb, tmin, tmax);
-        }
-#endif
-#endif
+        if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         if (fast) s_code[idx] = (uint16_t)code;
     } else if (MEASURE == ALL_MEASURES) {
         unsigned long long pk;
@@ -383,17 +325,13 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
-    constexpr bool MLUT = !LUT && stage_uses_mlut<MEASURE>();
     // The 1 KB behind each wave's tables holds 128 of the block's row descriptors (without tables: an array of their own).
-    static_assert(!LUT || STRSIM_STAGE_ALIAS != 0 || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
-    // (the small table: 1 KB per wave at a 1 KB boundary)
-    constexpr bool ALIAS = LUT && STRSIM_STAGE_ALIAS != 0;
-    static_assert(!ALIAS || 4096 * STAGE_WAVES <= 2 * STAGE_COL, "aliased tables lie inside the staging area");
-    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[(LUT && !ALIAS) ? 4096 * STAGE_WAVES : (MLUT ? MLUT_WAVE_BYTES * STAGE_WAVES : 16)];
-    __shared__ uint2 s_desc_own[(LUT && !ALIAS) ? 1 : B];
+    static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
+    __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : 16];
+    __shared__ uint2 s_desc_own[LUT ? 1 : B];
     __shared__ __attribute__((aligned(4096))) uint8_t s_bytes[2 * STAGE_COL + 64];
     auto desc_at = [&](uint32_t p) -> uint2 * { // descriptor of position p of the length order
-        if (LUT && !ALIAS) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
+        if (LUT) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
         return s_desc_own + p;
     };
     __shared__ __attribute__((aligned(16))) uint32_t s_off[2][B + 4]; // offsets of the rows from the next block's start on
@@ -477,7 +415,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 
     EqLut lut; // this wave's match-mask tables
     lut.lane4 = lane * 4u;
-    lut.krep = ((STRSIM_LDS_ADDR(ALIAS ? &s_bytes[0] : &s_lut[0]) >> 8) + (LUT ? 16u : 4u) * wv) * 0x01010101u;
+    lut.krep = ((STRSIM_LDS_ADDR(&s_lut[0]) >> 8) + 16u * wv) * 0x01010101u;
     const uint32_t ldsOffA = STRSIM_LDS_ADDR(&s_off[0][0]), ldsOffB = STRSIM_LDS_ADDR(&s_off[1][0]);
     const uint32_t ldsBytes = STRSIM_LDS_ADDR(&s_bytes[0]);
     const uint32_t wvu = uniform(wv);
@@ -539,17 +477,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
                 // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
                 // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
-#if STRSIM_STAGE_DIVIDE
-                // (variant: the division itself -- no dependent global load in the store phase, ~20 more vector instructions per
-                //  64 rows; code = dist * QTAB_N + den)
-                {
-                    const uint32_t c = (uint32_t)pk[q] == 0xFFFFu ? 1u : (uint32_t)pk[q];
-                    const uint32_t dist = c / (uint32_t)QTAB_N, den = c - dist * (uint32_t)QTAB_N;
-                    t0[q] = (double)dist / (double)(den ? den : 1u);
-                }
-#else
                 t0[q] = qtab[(uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q]];
-#endif
             } else if (JARO_LIKE) {
                 const uint32_t lo = (uint32_t)pk[q], hi = (uint32_t)(pk[q] >> 32);
                 const uint32_t m = (lo >> (ALL ? 6 : 0)) & 63u, t = (lo >> (ALL ? 12 : 6)) & 63u;
@@ -589,10 +517,6 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 }
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
-#ifdef STRSIM_EXP_NOSTORE
-                if (valid && !undone && v == 12345.0) outs.p[0][r0 + i] = v;
-                if (lane == 0u && valid && left == 0x1234ull) {
-#else
                 if (valid && !undone) {
                     if (ALL) {
 #pragma unroll
@@ -602,7 +526,6 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                     }
                 }
                 if (lane == 0u && valid) {
-#endif
                     maskb[i >> 6] = left;
                     if (publish && left) atomicAdd(&s_left, (uint32_t)__builtin_popcountll(left));
                 }
@@ -610,7 +533,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         }
     };
 
-#ifdef STRSIM_STAGE_STAMPS
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_last = st_t0;
@@ -623,12 +546,10 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             }
             grab_pending = false;
         }
-#if STRSIM_STAGE_STORE_FIRST
         // ---- B: store(j-1).  Before the bytes DMA of this block is issued: a wave's vector-memory results return in order,
         //         so the table loads of the store phase would otherwise sit behind its share of the DMA (HBM latency).
         if (prev_rows) store_block(prev_row0, prev_rows);
         STAGE_STAMP(1);
-#endif
         // ---- the block: as many of the next 64-row chunks (at most B / 64) as have their bytes inside the staging areas
         const uint32_t avail = (uint32_t)(row_end - row0 < (uint64_t)B ? row_end - row0 : (uint64_t)B); // rows whose offsets are in s_off
         const uint32_t baseA = bcastA ? litA0 : uniform(s_off[0][0]), baseB = bcastB ? litB0 : uniform(s_off[1][0]);
@@ -666,24 +587,13 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
 #pragma unroll
             for (int it = 0; it < STAGE_DMA_ITERS; ++it) {
-#ifdef STRSIM_EXP_NOBYTES
-                if (chunksA == 0x12345u)
-#endif
                 if (tid + (uint32_t)it * STAGE_BLOCK < chunksA)
                     lds_dma_b128(gA + 16 * it * STAGE_BLOCK, tid16, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
-#ifdef STRSIM_EXP_NOBYTES
-                if (chunksA == 0x12345u)
-#endif
                 if (tid + (uint32_t)it * STAGE_BLOCK < chunksB)
                     lds_dma_b128(gB + 16 * it * STAGE_BLOCK, tid16, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
             }
         }
         STAGE_STAMP(0);
-#if !STRSIM_STAGE_STORE_FIRST
-        // ---- B: store(j-1)
-        if (prev_rows) store_block(prev_row0, prev_rows);
-        STAGE_STAMP(1);
-#endif
         // ---- C: sortA(j): lengths -> bucket keys (number of DP columns the pair will run), ranks by LDS atomics
         uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT];
         {
@@ -702,11 +612,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
                 const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
                 skey[q] = key;
-#ifdef STRSIM_EXP_NOSORT
-                srank[q] = i; skey[q] = 0u;
-#else
                 srank[q] = atomicAdd(&s_cnt[key], 1u);
-#endif
                 sd0[q] = mine ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
                 sd1[q] = mine ? (lt | (lp << 8) | (i << 16)) : STAGE_DEAD;
             }
@@ -752,74 +658,29 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         if (next_row0 < row_end) dma_offsets(next_row0);
         STAGE_STAMP(6);
         // ---- F: rounds(j): wave w runs rounds w, 2W-1-w, 2W+w, ... of the length order (short + long = balanced)
-#if STRSIM_STAGE_PRIO
         __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
-#endif
-        if constexpr (ALIAS) {
-            // every window of the block into registers first, one more barrier, then the staging area holds the tables
-            uint32_t meta[STAGE_RPW];
-            uint32_t wts[STAGE_RPW][8], wps[STAGE_RPW][8];
-            bool run[STAGE_RPW];
-#if STRSIM_STAGE_PRIO_WINDOWS
-            __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
-#endif
-#pragma unroll
-            for (int k = 0; k < STAGE_RPW; ++k) {
-                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
-                run[k] = r * 64u < nmine;
-                if (run[k]) {
-                    const uint2 d = *desc_at(r * 64u + lane);
-                    meta[k] = d.y;
-                    stage_window(s_bytes, d.x & 0xFFFFu, wts[k]);
-                    stage_window(s_bytes, d.x >> 16, wps[k]);
-                }
-            }
-            STAGE_STAMP(7);
-            lds_barrier();
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int k = 0; k < STAGE_RPW; ++k) {
-                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
-                if (!run[k]) continue;
-                const uint32_t in_round = nmine - r * 64u; // (>= 1)
-                stage_compute<MEASURE, LUT>(lut, wts[k], wps[k], meta[k], (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
-                STAGE_STAMP(8);
-            }
-        } else {
+        {
 #pragma unroll 1
             for (int k = 0; k < STAGE_RPW; ++k) {
                 const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
-    #ifdef STRSIM_EXP_NOSORT
-                if (r * 64u >= rows) continue;
-    #else
                 if (r * 64u >= nmine) continue;
-    #endif
-    #ifdef STRSIM_EXP_NOROUNDS
-                if (nmine != 0x12345u) continue;
-    #endif
-    #if STRSIM_STAGE_PRIO_WINDOWS
-                __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
-    #endif
+                __builtin_amdgcn_s_setprio(1); // descriptor + window fetch ahead of the waves that grind columns
                 const uint2 d = *desc_at(r * 64u + lane);
                 uint32_t wt[8], wp[8];
                 stage_window(s_bytes, d.x & 0xFFFFu, wt);
                 stage_window(s_bytes, d.x >> 16, wp);
-    #if defined(STRSIM_STAGE_STAMPS) || defined(STRSIM_STAGE_LGKM)
+    #if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     #endif
                 STAGE_STAMP(7);
-    #if STRSIM_STAGE_PRIO_WINDOWS && !STRSIM_STAGE_PRIO_PLANES
                 __builtin_amdgcn_s_setprio(0);
-    #endif
                 const uint32_t in_round = nmine - r * 64u; // (>= 1)
                 stage_compute<MEASURE, LUT>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
                 STAGE_STAMP(8);
             }
         }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
-#if STRSIM_STAGE_PRIO
-        __builtin_amdgcn_s_setprio(STRSIM_STAGE_PRIO);
-#endif
+        __builtin_amdgcn_s_setprio(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         STAGE_STAMP(9);
@@ -849,7 +710,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             __hip_atomic_store(&sched[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-#ifdef STRSIM_STAGE_STAMPS
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
     if (lane == 0u) {
         const uint32_t w = (blockIdx.x * STAGE_WAVES + wv) & 16383u;
         for (int q = 0; q < 10; ++q) g_stage_stamps[w][q] = st_acc[q];

@@ -21,8 +21,12 @@ def device_count():
 class Context:
     """One GPU + one HIP stream + workspace (include/strsim_amd.h: strsim_ctx_t).  One per thread."""
 
-    def __init__(self, device=0, stream=None):
-        """`stream`: an int hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or None for an own non-blocking stream.
+    def __init__(self, device=0, stream=None, one_launch=False):
+        """`one_launch`: opt in to one-launch calls (strsim_ctx_set_stream_ordered(ctx, 0), ABI 1.4): a call that is expected to
+        need the first kernel only is enqueued as that kernel alone, and slow rows it turns out to hold are finished when the
+        call is retired -- for callers that synchronize() / retire_oldest() before they read results.  Default: every row of
+        strings <= 1024 bytes is complete in stream order.
+        `stream`: an int hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or None for an own non-blocking stream.
         Handle 0 -- torch's DEFAULT stream, `torch.cuda.current_stream().cuda_stream` outside a `torch.cuda.stream(s)`
         block -- is refused: the C ABI reads NULL as "create your own stream", so the context would silently run on a
         stream that torch-side events and copies are not ordered against.  Pass a real torch stream and do the torch-side
@@ -33,6 +37,8 @@ class Context:
         self._h = C.c_void_p()
         check(lib().strsim_ctx_create(int(device), C.c_void_p(int(stream)) if stream is not None else None, C.byref(self._h)))
         self.device = int(device)
+        if one_launch:
+            self.set_stream_ordered(False)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -84,8 +90,9 @@ class Context:
         return int(lib().strsim_ctx_enqueued_ops(self._h))
 
     def set_stream_ordered(self, enable=True):
-        """True: every call enqueues all its kernels up front, so results (strings <= 1024 bytes) are complete in stream
-        order -- for callers that consume them behind an event without retiring the call (strsim_ctx_set_stream_ordered)."""
+        """True (the default of a new context): every call enqueues all its kernels up front, so results (strings <= 1024
+        bytes) are complete in stream order -- for callers that consume them behind an event without retiring the call.
+        False: one-launch calls (see __init__).  Takes effect with the next call (strsim_ctx_set_stream_ordered)."""
         check(lib().strsim_ctx_set_stream_ordered(self._h, 1 if enable else 0))
 
     @property

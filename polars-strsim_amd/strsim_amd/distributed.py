@@ -76,8 +76,10 @@ class ShardGatherer:
             raise ValueError("ShardGatherer: ctx does not enqueue on compute_stream")
         # shipments read a step's results behind an event on the compute stream, without retiring the call first: every kernel of
         # a call must be on the stream when submit() is called (strsim_ctx_set_stream_ordered; one-launch calls would finish slow
-        # rows only at synchronize())
+        # rows only at synchronize()).  The context STAYS in stream-ordered mode; calls enqueued before this point in one-launch
+        # mode are retired here, so that nothing submitted later can be waiting for a late pass.
         ctx.set_stream_ordered(True)
+        ctx.synchronize()
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.parts = list(parts) if parts is not None else [(r * rows, rows) for r in range(self.world)]
         if len(self.parts) != self.world:

@@ -8,6 +8,7 @@
 #include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
 #include "strsim_lane_sym.h"
+#include "lane_core_textbook.h"
 
 using namespace strsim;
 
@@ -68,19 +69,13 @@ extern "C" uint32_t harness_lev_snap(const uint8_t *a, uint32_t la, const uint8_
         build_planes<5>(wb, P);
         lut_build<5>(t, P, 0xFFFFFFFFu);
         const uint32_t d = lev_myers32_snap<5>(wa, la, tmin, tmax, P, lb);
-        if (lev_myers32_lut<5>(t, wa, la, tmin, tmax, P, lb) != d) return 0xFFFFFFFFu;
-        EqLut tm{};
-        mlut_build<5>(tm, P, 0xFFFFFFFFu);
-        return lev_myers32_mlut<5>(tm, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFEu;
+        return lev_myers32_lut<5>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
     }
     uint32_t P[7];
     build_planes<7>(wb, P);
     lut_build<7>(t, P, 0xFFFFFFFFu);
     const uint32_t d = lev_myers32_snap<7>(wa, la, tmin, tmax, P, lb);
-    if (lev_myers32_lut<7>(t, wa, la, tmin, tmax, P, lb) != d) return 0xFFFFFFFFu;
-    EqLut tm{};
-    mlut_build<7>(tm, P, 0xFFFFFFFFu);
-    return lev_myers32_mlut<7>(tm, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFEu;
+    return lev_myers32_lut<7>(t, wa, la, tmin, tmax, P, lb) == d ? d : 0xFFFFFFFFu;
 }
 
 // the one-loop cores (lane_cores32) with all three cores on, and each of them on its own: out[0..3] = dist, m, t, isect of

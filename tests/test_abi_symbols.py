@@ -37,7 +37,7 @@ def test_versions():
     import strsim_amd
     from strsim_amd import arrow_host as H
     v = strsim_amd.lib().strsim_abi_version()
-    assert v >> 16 == 1 and (v & 0xFFFF) >= 3  # 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows)
+    assert v >> 16 == 1 and (v & 0xFFFF) >= 4  # 1.4: one-launch calls are opt-in (strsim_ctx_set_stream_ordered(ctx, 0))
     assert H.plugin_version() == (0, 1)
 
 

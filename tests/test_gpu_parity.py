@@ -596,7 +596,7 @@ def test_one_launch_calls_and_deferred_slow_rows(S, measure):
     call brings the context back to one launch.  Frames with 0, 1 and many slow rows, every result against the oracle."""
     frames = {k: _mixed_frame(S, k) for k in (0, 1, 700)}
     exp = {k: O.batch_strings(measure, f[0], f[1], 8) for k, f in frames.items()}
-    with S.Context(0) as ctx:
+    with S.Context(0, one_launch=True) as ctx:
         def call(k):
             before = ctx.enqueued_ops
             out = ctx.pairs_device(measure, *frames[k][2])
@@ -621,10 +621,54 @@ def test_one_launch_calls_and_deferred_slow_rows(S, measure):
             assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "%s, in flight, %d slow rows" % (measure, k))
 
 
+def test_pipelined_caller_with_early_copies_and_retire_oldest(S):
+    """The documented pattern of a pipelined caller in one-launch mode -- own event behind each call, an EARLY device-to-host
+    copy behind it, retire_oldest() in order, copy again when last_late_rows says a pass ran late -- with seven calls in flight:
+    the library never retires a call the caller has not asked it
+    to, so the k-th retire_oldest() is the k-th call, and every call whose slow rows were finished late says so."""
+    import torch
+    order = (0, 700, 1, 0, 700, 1, 700)
+    frames = {k: _mixed_frame(S, k) for k in set(order)}
+    exp = {k: O.batch_strings("jaro", f[0], f[1], 8) for k, f in frames.items()}
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), S.Context(0, stream=s.cuda_stream, one_launch=True) as ctx:
+        outs, early, evs, ops = [], [], [], []
+        for k in order:
+            before = ctx.enqueued_ops
+            outs.append(ctx.pairs_device("jaro", *frames[k][2]))
+            ops.append(ctx.enqueued_ops - before)
+            host = torch.empty(outs[-1].shape, dtype=torch.float64).pin_memory()
+            host.copy_(outs[-1], non_blocking=True)  # the early copy, on s behind the call
+            early.append(host)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        assert ops == [1] * len(order)  # every call is one launch: each owns its mask until the caller retires it
+        late_calls = 0
+        for i, k in enumerate(order):
+            evs[i].synchronize()
+            ctx.retire_oldest()
+            late = ctx.last_late_rows
+            if ops[i] == 1 and k:
+                assert late >= k, (i, k, late)   # this call's slow rows ran at ITS retirement ...
+            else:
+                assert late == 0, (i, k, late)   # ... and nobody else's are reported here
+            if late:
+                late_calls += 1
+                early[i].copy_(outs[i], non_blocking=True)
+                s.synchronize()
+            A, B = frames[k][0], frames[k][1]
+            assert_bit_exact(early[i].numpy(), exp[k], A, B, "pipelined caller, call %d (%d slow rows)" % (i, k))
+        assert late_calls >= 2
+        ctx.retire_oldest()  # nothing pending: a no-op
+        ctx.synchronize()
+    torch.cuda.synchronize()
+
+
 def test_fused_call_is_one_launch_without_slow_rows(S):
     A, B, cols = _mixed_frame(S, 0)
     A2, B2, cols2 = _mixed_frame(S, 50)
-    with S.Context(0) as ctx:
+    with S.Context(0, one_launch=True) as ctx:
         before = ctx.enqueued_ops
         outs = ctx.pairs_device_all(*cols)
         assert ctx.enqueued_ops - before == 1
@@ -640,14 +684,13 @@ def test_fused_call_is_one_launch_without_slow_rows(S):
 
 
 def test_stream_ordered_context_completes_in_stream_order(S):
-    """set_stream_ordered(True): the results of a frame WITH slow rows are complete for work enqueued behind the call on the
+    """The default mode of a context (set_stream_ordered(True), ABI 1.4): the results of a frame WITH slow rows are complete for work enqueued behind the call on the
     context's stream -- no retire in between (what bench.py's gather and any torch consumer on that stream rely on)."""
     import torch
     A, B, cols = _mixed_frame(S, 300)
     exp = O.batch_strings("jaro_winkler", A, B, 8)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s), S.Context(0, stream=s.cuda_stream) as ctx:
-        ctx.set_stream_ordered(True)
         before = ctx.enqueued_ops
         out = ctx.pairs_device("jaro_winkler", *cols)
         assert ctx.enqueued_ops - before == 5
@@ -711,7 +754,7 @@ def test_literal_calls_are_one_launch_too(S, measure, side):
         lo, lv = S.pack_strings([lit])
         lcols = (t(lo, np.int32), t(np.concatenate([lv, pad]), np.uint8))
         torch.cuda.synchronize()
-        with S.Context(0) as ctx:
+        with S.Context(0, one_launch=True) as ctx:
             before = ctx.enqueued_ops
             out = ctx.pairs_device(measure, *(lcols + cols[:2] if side == "a" else cols[:2] + lcols))
             assert ctx.enqueued_ops - before == (1 if (measure in ("jaro", "jaro_winkler") and side == "b") else 2)
@@ -785,7 +828,7 @@ def test_more_calls_in_flight_than_the_ring_holds(S):
     frames = {k: _mixed_frame(S, k) for k in (0, 40)}
     exp = {k: O.batch_strings("jaccard", f[0], f[1], 8) for k, f in frames.items()}
     order = [0, 0, 40, 0, 40, 40, 0] * 10
-    with S.Context(0) as ctx:
+    with S.Context(0, one_launch=True) as ctx:
         outs = [ctx.pairs_device("jaccard", *frames[k][2]) for k in order]
         ctx.synchronize()
         for o, k in zip(outs, order):

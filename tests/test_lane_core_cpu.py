@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "polars-strsim_amd", "csrc")
 @pytest.fixture(scope="module")
 def harness():
     so = os.path.join(HDIR, "liblane_core_harness.so")
-    srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h"),
+    srcs = [os.path.join(HDIR, "lane_core_harness.cpp"), os.path.join(CSRC, "strsim_lane_core.h"), os.path.join(HDIR, "lane_core_textbook.h"),
             os.path.join(CSRC, "strsim_lane_wide.h"), os.path.join(CSRC, "strsim_lane_sym.h"),
             os.path.join(CSRC, "strsim_lane_lut.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
