@@ -17,10 +17,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(ORACLE_DIR, "libstrsim_oracle.so")
-    src = os.path.join(ORACLE_DIR, "strsim_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    so = os.environ.get("STRSIM_ORACLE_LIB")  # (tests/run_sanitizers.sh: a sanitizer build of the oracle)
+    if not so:
+        so = os.path.join(ORACLE_DIR, "libstrsim_oracle.so")
+        src = os.path.join(ORACLE_DIR, "strsim_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     L = C.CDLL(so)
     L.oracle_pair.restype = C.c_double
     L.oracle_pair.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]

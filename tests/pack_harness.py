@@ -18,9 +18,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "polars-strsim_amd"), "testhooks"])
+        so = os.environ.get("STRSIM_TESTHOOKS_LIB")  # (tests/run_sanitizers.sh: a sanitizer build of the hooks)
+        if not so:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "polars-strsim_amd"), "testhooks"])
+            so = SO
         H._load()  # (maps the HIP runtime the way the product does, then the product library the hooks link against)
-        L = C.CDLL(SO)
+        L = C.CDLL(so)
         L._strsim_test_pack_series.restype = C.c_int
         L._strsim_test_pack_series.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_uint]
