@@ -9,16 +9,19 @@
 //
 //   bin      = (text columns in steps of 4) x (pattern length in steps of 16 bytes): every row of a bin runs the same number of
 //              column groups at the same mask width with the same slot sizes -- no sort, no idle columns beyond the rounding;
-//   page     = 64 rows of one bin = one round of one wave of k_wide_bins: 64 row indices + 64 length bytes, then the rows' strings
-//              in 16-byte pieces, piece by piece (piece q of the 64 rows lies together; text pieces first, then the pattern's:
-//              both rounded up to whole pieces by the bin): a wave instruction of the reader loads one piece of all 64 rows,
-//              1 KB contiguous, straight into the lanes' registers;
+//   page     = 64 rows of one bin = one round of one wave of k_wide_bins: 64 RECORDS of 16 bytes (row, where its text starts,
+//              where its pattern starts, the two lengths within the bin's ranges) -- 1 KB, one coalesced load per round.  The
+//              strings themselves stay where they are: the reader's lanes fetch their own rows' pieces from the columns while
+//              the round in front computes.  (Pages that carried the rows' BYTES -- slots filled out of k_lane_stage's staging
+//              area -- were built first and measured, profiles/r4_cfg3_fullcopy_bins_summary.txt: the reader's side was all one
+//              could wish for, but 36 M rows x 9 pieces are 313 M scattered 16-byte stores on the writer's side: 3.1e9 busy
+//              cycles of the address units per launch, six times what the kernel spends otherwise, 10.8 GB written for 4.9 GB
+//              of pages, k_lane_stage 2.65 -> 6.0 ms.  A GPU gathers well and scatters badly.)
 //   position = a row's place in its bin is known before k_lane_stage starts: k_bin_hist counts the rows of every bin per GROUP of
 //              2 048 rows (lengths only: one pass over the offsets), k_bin_top / k_bin_base turn the counts into exclusive
 //              prefixes, and a workgroup of k_lane_stage that takes a group gets the group's first position in every bin -- no
-//              device-wide atomics, no over-allocation, every slot of a bin accounted for (a row whose bytes are not in the
-//              staging area after all leaves a DEAD record and stays in the mask; a row k_wide_bins finds non-ASCII gets its
-//              mask bit back from there -- the code-point kernels run behind it).
+//              device-wide atomics, no over-allocation, every record of a bin accounted for (a row k_wide_bins finds non-ASCII
+//              gets its mask bit back from there -- the code-point kernels run behind it).
 //
 // Reference semantics are untouched: which rows are binned depends on byte lengths only, and a binned row's result comes from
 // the same W-word cores (strsim_lane_wide.h; strsim.rs:141-160, :200-237, :297-305, :333-341).
@@ -35,8 +38,9 @@ constexpr int BIN_GROUP_CHUNKS = BIN_GROUP_ROWS / 64;
 constexpr int BIN_COUNT = 256;                  // (text bucket 0..31) * 8 + (pattern class 0..7)
 constexpr int BIN_SEG_GROUPS = 64;              // groups per segment of the two-level prefix sum
 constexpr int BIN_CLASSES = 3;                  // mask widths 2 / 3 / 4 words
-constexpr uint32_t BIN_PAGE_HEAD16 = 20;        // page header in 16-byte units: 64 x u32 row + 64 x u8 lengths
-constexpr uint32_t BIN_DEAD_ROW = 0xFFFFFFFFu;  // record of a slot whose row was not copied (stays in the mask)
+constexpr uint32_t BIN_PAGE16 = 64;             // a page in 16-byte units: 64 records
+constexpr uint32_t BIN_DEAD_ROW = 0xFFFFFFFFu;  // record word 0 of a row that was not handed over after all (it stays in the mask)
+constexpr uint32_t BIN_REC_TEXT_IN_B = 0x80u;   // record word 3: the text is the row's string of column b (symmetric measures walk the shorter one)
 static_assert(BIN_SEG_GROUPS % 16 == 0, "k_bin_base walks a segment sixteen groups at a time");
 
 // A row is a CANDIDATE for the bins by its byte lengths alone (what k_lane_wide takes: the longer side 33..128, neither empty).
@@ -49,10 +53,8 @@ STRSIM_HD bool bin_candidate(uint32_t la8, uint32_t lb8)
 STRSIM_HD uint32_t bin_of(uint32_t lt, uint32_t lp) { return (((lt - 1u) >> 2) << 3) | ((lp - 1u) >> 4); }
 STRSIM_HD uint32_t bin_text_bucket(uint32_t bin) { return bin >> 3; }                 // the text has 4 tb + 1 .. 4 tb + 4 bytes
 STRSIM_HD uint32_t bin_pat_class(uint32_t bin) { return bin & 7u; }                   // the pattern has 16 pc + 1 .. 16 pc + 16 bytes
-STRSIM_HD uint32_t bin_text_slot16(uint32_t bin) { return (bin >> 5) + 1u; }          // slot of the text, 16-byte units (1..8)
-STRSIM_HD uint32_t bin_pat_slot16(uint32_t bin) { return (bin & 7u) + 1u; }           // slot of the pattern
-STRSIM_HD uint32_t bin_slot16(uint32_t bin) { return bin_text_slot16(bin) + bin_pat_slot16(bin); }
-STRSIM_HD uint32_t bin_page16(uint32_t bin) { return BIN_PAGE_HEAD16 + 64u * bin_slot16(bin); }
+STRSIM_HD uint32_t bin_text_pieces(uint32_t bin) { return (bin >> 5) + 1u; }          // 16-byte pieces that cover the text (1..8)
+STRSIM_HD uint32_t bin_pat_pieces(uint32_t bin) { return (bin & 7u) + 1u; }           // ... the pattern
 // mask words of the bin's rows: by the PATTERN (the masks are over pattern positions), at least two
 STRSIM_HD uint32_t bin_words(uint32_t bin) { const uint32_t w = ((bin & 7u) >> 1) + 1u; return w < 2u ? 2u : w; }
 STRSIM_HD uint32_t bin_class(uint32_t bin) { return bin_words(bin) - 2u; }
@@ -88,20 +90,31 @@ __global__ __launch_bounds__(256) void k_bin_hist(const uint32_t *__restrict__ o
     uint32_t acc = 0u;
     s_h[tid] = 0u;
     __syncthreads();
+    static_assert(BIN_GROUP_ROWS == 8 * 256, "k_bin_hist: eight consecutive rows per thread");
     for (uint64_t g = g0; g < g0 + BIN_SEG_GROUPS && g < ngroups; ++g) {
-        const uint64_t r0 = g * BIN_GROUP_ROWS;
+        // thread t: rows 8 t .. 8 t + 7 of the group -- nine consecutive offsets per column, two 16-byte loads and one dword
+        const uint64_t r0 = g * BIN_GROUP_ROWS + 8u * tid;
+        if (r0 + 8u <= n && ((reinterpret_cast<uintptr_t>(offA + r0) | reinterpret_cast<uintptr_t>(offB + r0)) & 15u) == 0u) {
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(offA + r0), a1 = *reinterpret_cast<const uint4 *>(offA + r0 + 4);
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(offB + r0), b1 = *reinterpret_cast<const uint4 *>(offB + r0 + 4);
+            const uint32_t oa[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, offA[r0 + 8]};
+            const uint32_t ob[9] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, offB[r0 + 8]};
 #pragma unroll
-        for (int k = 0; k < BIN_GROUP_ROWS / 256; ++k) {
-            const uint64_t row = r0 + (uint64_t)k * 256u + tid;
-            uint32_t bin = 0xFFFFFFFFu;
-            if (row < n) {
-                const uint32_t la8 = offA[row + 1] - offA[row], lb8 = offB[row + 1] - offB[row];
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t la8 = oa[k + 1] - oa[k], lb8 = ob[k + 1] - ob[k];
                 if (bin_candidate(la8, lb8)) {
                     const bool swap = SYMMETRIC && la8 > lb8; // symmetric measures walk the shorter string
-                    bin = bin_of(swap ? lb8 : la8, swap ? la8 : lb8);
+                    atomicAdd(&s_h[bin_of(swap ? lb8 : la8, swap ? la8 : lb8)], 1u);
                 }
             }
-            if (bin != 0xFFFFFFFFu) atomicAdd(&s_h[bin], 1u);
+        } else {
+            for (uint64_t row = r0; row < r0 + 8u && row < n; ++row) {
+                const uint32_t la8 = offA[row + 1] - offA[row], lb8 = offB[row + 1] - offB[row];
+                if (bin_candidate(la8, lb8)) {
+                    const bool swap = SYMMETRIC && la8 > lb8;
+                    atomicAdd(&s_h[bin_of(swap ? lb8 : la8, swap ? la8 : lb8)], 1u);
+                }
+            }
         }
         __syncthreads();
         const uint32_t v = s_h[tid];
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bin_top(uint32_t *__restrict__ seg, uin
         unsigned long long at16 = 0ull, rows = 0ull;
         for (uint32_t q = 0; q < (uint32_t)BIN_COUNT; ++q) {
             table->base16[q] = at16 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)at16;
-            at16 += (unsigned long long)((s_cnt[q] + 63u) >> 6) * bin_page16(q);
+            at16 += (unsigned long long)((s_cnt[q] + 63u) >> 6) * BIN_PAGE16;
             rows += s_cnt[q];
         }
         const uint32_t total16 = at16 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)at16;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void k_bin_base(uint32_t *__restrict__ hist, c
 struct BinArgs {
     const uint32_t *base;   // [group][bin]: the group's first position in the bin
     const BinTable *table;
-    uint8_t *buf;           // the bins buffer (pages)
+    uint4 *buf;             // the bins buffer (pages of records)
 };
 
 #endif // __HIPCC__

@@ -102,14 +102,12 @@ struct strsim_ctx {
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
     uint32_t *scan_ws = nullptr;     // block sums of strsim_offsets_from_lengths (SCAN_WS_WORDS, allocated on first use)
-    // binned mode (strsim_bins.h): pages for the rows of 33..128 bytes + the layout scratch (grow-only, allocated on first use)
+    // binned mode (strsim_bins.h): pages of records for the rows of 33..128 bytes + the layout scratch (grow-only, allocated on first use)
     void *bins_buf = nullptr;
     size_t bins_cap = 0;             // bytes
     void *bin_table = nullptr;
     uint32_t *bin_hist = nullptr, *bin_seg = nullptr;
     size_t bin_hist_cap = 0, bin_seg_cap = 0;
-    uint64_t bins_want16 = 0;        // what the last retired call's bins took (16-byte units; 0: unknown) and ...
-    uint64_t bins_want_rows = 0;     // ... for how many rows of the call
     int head = 0;
     double *qtab = nullptr;          // QTAB_N x QTAB_N quotients a / b (strsim_lane_core.h), filled at creation
     uint64_t last_wave_rows = 0;
@@ -245,8 +243,6 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
         const uint32_t binned = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].bins_rows);
         c->expect_slow = left != 0u || binned != 0u;
         c->long_rows = ((uint64_t)left + binned) * 16u > c->slot_args[s].n;
-        const uint32_t want16 = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].bins_total16);
-        if (want16) { c->bins_want16 = want16; c->bins_want_rows = c->slot_args[s].n; }
         c->last_binned_rows = binned;
     }
     if (c->slot_timed[s]) {
@@ -527,8 +523,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         la.lev_ws = c->lev_ws;
     }
     // Binned mode: a frame with many rows of 33..128 bytes (the context's last call said so), two columns, one measure.  The
-    // buffer is sized by what the last such call's bins took, scaled to this call's rows (first time: 64 bytes per row); a frame
-    // that does not fit is simply not binned (k_bin_top decides on the device) and tells what it would have taken.
+    // buffer holds a 16-byte record per row and a page of padding per bin: enough whatever the frame holds.
     la.use_bins = false;
     la.num_cu = c->num_cu;
     la.bins_buf = nullptr; la.bins_cap16 = 0u; la.bin_table = nullptr; la.bin_hist = nullptr; la.bin_seg = nullptr;
@@ -536,17 +531,15 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         const char *const mre = getenv("STRSIM_BINS_MIN_ROWS"); // (tuning knob, read per call: tests lower it)
         const uint64_t min_rows = mre ? (uint64_t)strtoull(mre, nullptr, 10) : (uint64_t)1 << 20;
         if (!all && !eager && !defer && c->long_rows && a_rows == b_rows && n >= min_rows && !getenv("STRSIM_NO_BINS")) {
-            uint64_t want16 = c->bins_want16 ? (uint64_t)((double)c->bins_want16 * ((double)n / (double)(c->bins_want_rows ? c->bins_want_rows : n)) * 1.0625) + 4096u
-                                             : n * 4u; // 64 bytes per row
-            if (want16 > 0xFFFFFFF0ull) want16 = 0xFFFFFFF0ull;
-            bool ok = true;
+            const uint64_t want16 = n + 64u * 256u;
+            bool ok = want16 <= 0xFFFFFFF0ull;
             auto reserve = [&](void **p, size_t *cap, size_t bytes) { // (out of memory: not an error, the call takes the other path)
                 if (!ok) return;
                 const int r = ctx_reserve(p, cap, bytes);
                 if (r == STRSIM_ERR_OOM) { (void)hipGetLastError(); ok = false; }
                 else if (r) { rc = r; ok = false; }
             };
-            if (c->bins_cap < want16 * 16u) reserve(&c->bins_buf, &c->bins_cap, (size_t)want16 * 16u);
+            reserve(&c->bins_buf, &c->bins_cap, (size_t)want16 * 16u);
             reserve((void **)&c->bin_hist, &c->bin_hist_cap, bin_hist_words(n) * sizeof(uint32_t));
             reserve((void **)&c->bin_seg, &c->bin_seg_cap, bin_seg_words(n) * sizeof(uint32_t));
             if (ok && !c->bin_table) {

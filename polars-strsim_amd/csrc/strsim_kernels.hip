@@ -2005,7 +2005,7 @@ static void launch_lane_t(const LaunchArgs &a)
         if (gs > ngroups) gs = ngroups; // (a workgroup's unit is a group)
         hipLaunchKernelGGL((k_lane_stage_bins<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                            a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket,
-                           BinArgs{a.bin_hist, table, a.bins_buf});
+                           BinArgs{a.bin_hist, table, reinterpret_cast<uint4 *>(a.bins_buf)});
     } else {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
@@ -2046,12 +2046,13 @@ template <int M>
 static void launch_wide_bins(const LaunchArgs &a, double *out)
 {
     const BinTable *const table = static_cast<const BinTable *>(a.bin_table);
+    const uint4 *const recs = reinterpret_cast<const uint4 *>(a.bins_buf);
     static const bool lut = [] { const char *e = getenv("STRSIM_BINS_LUT"); return e ? atoi(e) != 0 : true; }(); // (A/B knob)
     auto go = [&](auto use_lut) {
         constexpr bool L = decltype(use_lut)::value;
-        hipLaunchKernelGGL((k_wide_bins<M, 4, L>), dim3(wide_bins_grid<M, 4, L>(a.num_cu)), dim3(64), 0, a.stream, table, a.bins_buf, out, a.slowmask);
-        hipLaunchKernelGGL((k_wide_bins<M, 3, L>), dim3(wide_bins_grid<M, 3, L>(a.num_cu)), dim3(64), 0, a.stream, table, a.bins_buf, out, a.slowmask);
-        hipLaunchKernelGGL((k_wide_bins<M, 2, L>), dim3(wide_bins_grid<M, 2, L>(a.num_cu)), dim3(64), 0, a.stream, table, a.bins_buf, out, a.slowmask);
+        hipLaunchKernelGGL((k_wide_bins<M, 4, L>), dim3(wide_bins_grid<M, 4, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
+        hipLaunchKernelGGL((k_wide_bins<M, 3, L>), dim3(wide_bins_grid<M, 3, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
+        hipLaunchKernelGGL((k_wide_bins<M, 2, L>), dim3(wide_bins_grid<M, 2, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
     };
     if (lut) go(std::true_type{}); else go(std::false_type{});
 }

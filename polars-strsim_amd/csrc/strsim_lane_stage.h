@@ -36,7 +36,7 @@
 #define STRSIM_STAGE_CAP_LUT 8960 // the same for the instantiations with match-mask tables (40 KB of LDS: four workgroups per CU)
 #endif
 #ifndef STRSIM_STAGE_CAP_BINS
-#define STRSIM_STAGE_CAP_BINS 8608 // the same in binned mode (4 KB of LDS for the bins' cursors, positions and page bases: still five workgroups per CU)
+#define STRSIM_STAGE_CAP_BINS 8608 // the same in binned mode (4 KB of LDS for the bins' cursors, positions and bases: still five workgroups per CU)
 #endif
 #ifndef STRSIM_STAGE_WAVES_PER_EU
 #define STRSIM_STAGE_WAVES_PER_EU 5
@@ -135,8 +135,9 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // "text" is the string the columns of the bit-parallel cores walk: a, or the shorter one for the symmetric measures
 // when both sides are columns.
 constexpr uint32_t STAGE_DEAD = 1u << 31;
-// binned mode, rows this kernel hands over (lengths up to 128: 8 bits each): a candidate for the bins; one whose bytes are not all
-// inside the staging area (a chunk that alone overflows it): its slot gets a dead record and the row stays in the mask
+// binned mode, rows this kernel hands over (lengths up to 128: 8 bits each): a candidate for the bins; one whose strings do not lie
+// inside the staging area (a chunk that alone overflows it: the descriptor's 16-bit addresses cannot say where they are): its
+// record is marked dead and the row stays in the mask
 constexpr uint32_t STAGE_CAND = 1u << 30, STAGE_NOCOPY = 1u << 29;
 constexpr uint32_t STAGE_BINNED16 = 0xFFFEu, STAGE_BINNED32 = 0xFFFFFFFEu; // staged "result" of a row that went to the bins
 
@@ -710,37 +711,24 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         if (next_row0 < row_end) dma_offsets(next_row0);
         STAGE_STAMP(6);
         if constexpr (BINS) {
-            // ---- E': the block's candidates for the bins leave through their page slots (strsim_bins.h): sixteen lanes per row, a
-            //          16-byte piece of the text or of the pattern each, as it lies in the staging area (what follows a string's end
-            //          inside its last piece are its neighbour's bytes; k_wide_bins, like the rounds below, tests whole pieces for
-            //          high bits and varying bits: conservative, never wrong).  One unaligned 16-byte LDS read per lane: gfx950
-            //          serves it a lane at a time (bench_support/micro/lds_window.hip), which costs LDS time this kernel has, not
-            //          the vector issue it is short of.
-            const uint32_t q = lane & 15u;
-            for (uint32_t p0 = nmine + 4u * wv; p0 < nmine + ncand; p0 += 4u * (uint32_t)STAGE_WAVES) {
-                const uint32_t p = p0 + (lane >> 4);
-                const bool on = p < nmine + ncand;
-                const uint32_t pp = on ? p : nmine;
-                const uint2 d = *desc_at(pp);
-                const uint32_t pos = s_pos[pp];
+            // ---- E': the block's candidates for the bins leave as RECORDS (strsim_bins.h): the row, where its text and its pattern
+            //          start in their columns, the two lengths within the bin's ranges -- one 16-byte store per row.
+            for (uint32_t p = nmine + tid; p < nmine + ncand; p += (uint32_t)STAGE_BLOCK) {
+                const uint2 d = *desc_at(p);
+                const uint32_t pos = s_pos[p];
                 const uint32_t lt = d.y & 0xFFu, lp = (d.y >> 8) & 0xFFu, idx = (d.y >> 16) & 0x1FFu;
-                const uint32_t bin = bin_of(lt, lp), ts = bin_text_slot16(bin), sl = ts + bin_pat_slot16(bin);
-                const uint32_t at16 = s_base16[bin] + (pos >> 6) * (BIN_PAGE_HEAD16 + 64u * sl); // the page, 16-byte units
+                const uint32_t bin = bin_of(lt, lp);
+                // the descriptor holds staging-area addresses: column a's area starts at 0, column b's at COLB
+                const uint32_t wt = d.x & 0xFFFFu, wp = d.x >> 16;
+                const bool t_in_b = wt >= COLB;
+                const uint32_t toff = t_in_b ? baseB - misB + (wt - COLB) : baseA - misA + wt;
+                const uint32_t poff = t_in_b ? baseA - misA + wp : baseB - misB + (wp - COLB);
                 const bool dead = (d.y & STAGE_NOCOPY) != 0u;
-                const bool piece = on && q < sl && !dead, istext = q < ts;
-                const uint32_t src = (istext ? (d.x & 0xFFFFu) : (d.x >> 16) - 16u * ts) + 16u * q;
-                const u32x4_unaligned w = *reinterpret_cast<const u32x4_unaligned *>(s_bytes + (piece ? src : 0u));
-                uint8_t *const pg = bins.buf + (size_t)at16 * 16u;
-                const uint32_t slot = pos & 63u;
-                if (piece) // piece q of the page's 64 rows lies together: the reader's lanes load 1 KB per instruction
-                    *reinterpret_cast<uint4 *>(pg + 16u * (BIN_PAGE_HEAD16 + q * 64u + slot)) = make_uint4(w.x, w.y, w.z, w.w);
-                if (on && q == 0u) {
-                    reinterpret_cast<uint32_t *>(pg)[slot] = dead ? BIN_DEAD_ROW : (uint32_t)(row0 + idx);
-                    pg[256u + slot] = (uint8_t)bin_len_byte(lt, lp);
-                    if (!dead) {
-                        if (LEV) s_code[idx] = (uint16_t)STAGE_BINNED16;
-                        else s_word[idx] = STAGE_BINNED32;
-                    }
+                bins.buf[(size_t)s_base16[bin] + pos] =
+                    make_uint4(dead ? BIN_DEAD_ROW : (uint32_t)(row0 + idx), toff, poff, bin_len_byte(lt, lp) | (t_in_b ? BIN_REC_TEXT_IN_B : 0u));
+                if (!dead) {
+                    if (LEV) s_code[idx] = (uint16_t)STAGE_BINNED16;
+                    else s_word[idx] = STAGE_BINNED32;
                 }
             }
         }

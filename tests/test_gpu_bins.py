@@ -1,5 +1,5 @@
 """GPU parity of the BINNED path for rows of 33..128 ASCII bytes (csrc/strsim_bins.h, strsim_lane_bins.h): k_lane_stage hands
-those rows to k_wide_bins through pages of 64 rows of one bin.  A context takes that path when its previous call left many such
+those rows to k_wide_bins through pages of 64 records of one bin.  A context takes that path when its previous call left many such
 rows, so every test runs a frame twice on one context -- first through the mask-driven kernels, then binned -- and holds both
 to the oracle bit for bit (reference semantics: strsim.rs:141-160, :200-237, :257-270, :297-305, :333-341).
 """
@@ -97,10 +97,8 @@ def test_binned_rows_match_the_oracle(S, measure):
             ctx.synchronize()
             binned.append(ctx.last_binned_rows)
             assert_bit_exact(out.cpu().numpy(), exp, A, B, "%s, call %d (%d rows binned)" % (measure, rep + 1, binned[-1]))
-        # (this frame's bins take more than the 64 bytes per row the first binned call guesses: that call is told so on the device
-        #  and runs unbinned; from then on the buffer is sized by what the frame needs.)  Every ASCII candidate goes through the
-        # bins; the others keep their mask bit for the code-point kernels.
-        assert binned[0] in (0, binned[1]) and binned[1] == binned[2] >= ncand_ascii, (binned, ncand_ascii)
+        # every candidate goes through the bins (k_wide_bins hands the non-ASCII ones back through the mask)
+        assert binned[0] == binned[1] == binned[2] >= ncand_ascii, (binned, ncand_ascii)
 
 
 @pytest.mark.parametrize("measure", ["levenshtein", "jaro_winkler"])
@@ -125,23 +123,32 @@ def test_frames_of_every_density_and_size(S, measure):
                 ctx.synchronize()
                 binned.append(ctx.last_binned_rows)
                 assert_bit_exact(out.cpu().numpy(), exp, A, B, "%s, %s, call %d" % (measure, what, rep))
-            assert binned[0] == 0 and binned[2] > 0 and binned[3] == binned[2], (what, binned)
+            assert binned[0] == 0 and binned[1] > 0 and binned[3] == binned[2] == binned[1], (what, binned)
 
 
-def test_a_frame_that_outgrows_the_buffer_is_not_binned_and_the_next_one_is(S):
-    """The first binned call sizes the buffer by a guess (64 bytes per row); a frame of 128-byte pairs needs four times that:
-    k_bin_top says no on the device, the call runs through the mask-driven kernels, and the call after it has what it needs."""
+def test_the_longest_pairs_and_the_last_rows_of_the_columns(S):
+    """128-byte pairs (the widest masks, eight pieces a side); the frame's last rows end at the columns' last bytes, where a
+    row's last 16-byte piece reaches past the column (read byte by byte there)."""
     A, B = gen.pairs(61, 3000, gen.ASCII_LOWER, 120, 128, max_bytes=128)
-    exp = O.batch_strings("jaccard", A, B, 8)
-    cols = to_device(S, A, B)
-    with S.Context(0) as ctx:
-        seen = []
-        for rep in range(3):
-            out = ctx.pairs_device("jaccard", *cols)
-            ctx.synchronize()
-            seen.append(ctx.last_binned_rows)
-            assert_bit_exact(out.cpu().numpy(), exp, A, B, "jaccard, call %d" % rep)
-        assert seen[0] == 0 and seen[1] == 0 and seen[2] == len(A), seen
+    A += ["q" * 33, "r" * 37]
+    B += ["q" * 34, "rs" * 17]
+    import torch
+    oa, va = S.pack_strings(A)
+    ob, vb = S.pack_strings(B)
+    dev = torch.device("cuda", 0)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    cols = (t(oa, np.int32), t(va, np.uint8), t(ob, np.int32), t(vb, np.uint8))  # (no padding behind the columns)
+    torch.cuda.synchronize()
+    for measure in ("jaccard", "jaro"):
+        exp = O.batch_strings(measure, A, B, 8)
+        with S.Context(0) as ctx:
+            seen = []
+            for rep in range(3):
+                out = ctx.pairs_device(measure, *cols)
+                ctx.synchronize()
+                seen.append(ctx.last_binned_rows)
+                assert_bit_exact(out.cpu().numpy(), exp, A, B, "%s, call %d" % (measure, rep))
+            assert seen == [0, len(A), len(A)], seen
 
 
 def test_the_context_falls_back_when_the_long_rows_are_gone(S):
