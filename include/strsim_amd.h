@@ -209,11 +209,6 @@ STRSIM_API int strsim_ctx_retire_oldest(strsim_ctx_t *ctx);
  * (valid after strsim_ctx_synchronize()). */
 STRSIM_API uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *ctx);
 
-/* Rows the last retired call handed from the one-pair-per-lane kernel to the binned kernels for strings of 33..128 ASCII bytes
- * (0: the call was not binned -- few such rows in the context's previous call, a literal side, the five-measure call, a small
- * frame; introspection for tests and benches, ABI 1.4). */
-STRSIM_API uint64_t strsim_ctx_last_binned_rows(strsim_ctx_t *ctx);
-
 /* Rows of the calls retired by the last strsim_ctx_synchronize() / strsim_ctx_retire_oldest() that held a string longer than
  * STRSIM_WAVE_PATH_MAX_BYTES: their results were written by the second pass that synchronize runs, i.e. AFTER anything
  * the caller enqueued on the stream behind the call (a caller that copies results out early re-copies when > 0). */

@@ -102,16 +102,9 @@ struct strsim_ctx {
     uint32_t *huge_ws = nullptr;     // workspace of the long-string pass (grow-only)
     size_t huge_ws_cap = 0;
     uint32_t *scan_ws = nullptr;     // block sums of strsim_offsets_from_lengths (SCAN_WS_WORDS, allocated on first use)
-    // binned mode (strsim_bins.h): pages of records for the rows of 33..128 bytes + the layout scratch (grow-only, allocated on first use)
-    void *bins_buf = nullptr;
-    size_t bins_cap = 0;             // bytes
-    void *bin_table = nullptr;
-    uint32_t *bin_hist = nullptr, *bin_seg = nullptr;
-    size_t bin_hist_cap = 0, bin_seg_cap = 0;
     int head = 0;
     double *qtab = nullptr;          // QTAB_N x QTAB_N quotients a / b (strsim_lane_core.h), filled at creation
     uint64_t last_wave_rows = 0;
-    uint64_t last_binned_rows = 0; // rows the last retired call handed to k_wide_bins
     uint64_t last_long_rows = 0; // over the slots retired by the last synchronize
     // staging for strsim_pairs_host (grow-only device buffers)
     void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -239,11 +232,8 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
     }
     const uint32_t left = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].lane_left);
     if (left != LANE_LEFT_UNKNOWN) { // what the next call on this context is enqueued for
-        // (rows that went to the bins were not "left" by the lane kernel, but they are rows of 33..128 bytes all the same)
-        const uint32_t binned = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].bins_rows);
-        c->expect_slow = left != 0u || binned != 0u;
-        c->long_rows = ((uint64_t)left + binned) * 16u > c->slot_args[s].n;
-        c->last_binned_rows = binned;
+        c->expect_slow = left != 0u;
+        c->long_rows = (uint64_t)left * 16u > c->slot_args[s].n;
     }
     if (c->slot_timed[s]) {
         float a = 0, b = 0;
@@ -400,10 +390,6 @@ void strsim_ctx_destroy(strsim_ctx_t *c)
     if (c->sched) (void)hipFree(c->sched);
     if (c->huge_ws) (void)hipFree(c->huge_ws);
     if (c->scan_ws) (void)hipFree(c->scan_ws);
-    if (c->bins_buf) (void)hipFree(c->bins_buf);
-    if (c->bin_table) (void)hipFree(c->bin_table);
-    if (c->bin_hist) (void)hipFree(c->bin_hist);
-    if (c->bin_seg) (void)hipFree(c->bin_seg);
     if (c->lev_ws) (void)hipFree(c->lev_ws);
     if (c->status) (void)hipFree(c->status);
     if (c->status_host) (void)hipHostFree(c->status_host);
@@ -522,39 +508,6 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         if (rc) return rc;
         la.lev_ws = c->lev_ws;
     }
-    // Binned mode: a frame with many rows of 33..128 bytes (the context's last call said so), two columns, one measure.  The
-    // buffer holds a 16-byte record per row and a page of padding per bin: enough whatever the frame holds.
-    la.use_bins = false;
-    la.num_cu = c->num_cu;
-    la.bins_buf = nullptr; la.bins_cap16 = 0u; la.bin_table = nullptr; la.bin_hist = nullptr; la.bin_seg = nullptr;
-    {
-        const char *const mre = getenv("STRSIM_BINS_MIN_ROWS"); // (tuning knob, read per call: tests lower it)
-        const uint64_t min_rows = mre ? (uint64_t)strtoull(mre, nullptr, 10) : (uint64_t)1 << 20;
-        if (!all && !eager && !defer && c->long_rows && a_rows == b_rows && n >= min_rows && !getenv("STRSIM_NO_BINS")) {
-            const uint64_t want16 = n + 64u * 256u;
-            bool ok = want16 <= 0xFFFFFFF0ull;
-            auto reserve = [&](void **p, size_t *cap, size_t bytes) { // (out of memory: not an error, the call takes the other path)
-                if (!ok) return;
-                const int r = ctx_reserve(p, cap, bytes);
-                if (r == STRSIM_ERR_OOM) { (void)hipGetLastError(); ok = false; }
-                else if (r) { rc = r; ok = false; }
-            };
-            reserve(&c->bins_buf, &c->bins_cap, (size_t)want16 * 16u);
-            reserve((void **)&c->bin_hist, &c->bin_hist_cap, bin_hist_words(n) * sizeof(uint32_t));
-            reserve((void **)&c->bin_seg, &c->bin_seg_cap, bin_seg_words(n) * sizeof(uint32_t));
-            if (ok && !c->bin_table) {
-                hipError_t e = hipMalloc(&c->bin_table, bin_table_bytes());
-                if (e != hipSuccess) { (void)hipGetLastError(); ok = false; }
-            }
-            if (rc) return rc;
-            if (ok) {
-                la.use_bins = true;
-                la.bins_buf = static_cast<uint8_t *>(c->bins_buf);
-                la.bins_cap16 = (uint32_t)std::min<uint64_t>(c->bins_cap / 16u, 0xFFFFFFF0ull);
-                la.bin_table = c->bin_table; la.bin_hist = c->bin_hist; la.bin_seg = c->bin_seg;
-            }
-        }
-    }
     la.ev_lane0 = la.ev_lane1 = la.ev_wave1 = nullptr;
     if (c->timing) {
         for (int i = 0; i < 3; ++i)
@@ -605,7 +558,7 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     }
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     // lane kernel (+ k_publish_lit behind k_lane_lit) | + three slow-row kernels (x 5, + 5 mask copies) + status copy
-    c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la) + (defer ? 0u : (all ? 21u : 4u)) + (la.use_bins ? 3u : 0u);
+    c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la) + (defer ? 0u : (all ? 21u : 4u));
     c->slot_timed[slot] = c->timing;
     c->slot_deferred[slot] = defer;
     if (defer) c->maskbuf_owner[mb] = slot;
@@ -787,7 +740,6 @@ int strsim_ctx_timing_read(strsim_ctx_t *c, double *lane_ms, uint64_t *lane_laun
 
 uint64_t strsim_ctx_last_wave_rows(strsim_ctx_t *c) { return c ? c->last_wave_rows : 0; }
 uint64_t strsim_ctx_last_long_rows(strsim_ctx_t *c) { return c ? c->last_long_rows : 0; }
-uint64_t strsim_ctx_last_binned_rows(strsim_ctx_t *c) { return c ? c->last_binned_rows : 0; }
 uint64_t strsim_ctx_last_late_rows(strsim_ctx_t *c) { return c ? c->last_late_rows : 0; }
 uint64_t strsim_ctx_enqueued_ops(strsim_ctx_t *c) { return c ? c->enqueued_ops : 0; }
 

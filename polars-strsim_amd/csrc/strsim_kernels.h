@@ -45,9 +45,7 @@ struct DevStatus {
     unsigned int list_count[5]; // k_lane_utf8: chunks of 64 rows that still hold unfinished rows ...
     unsigned int list_rows[5];  // ... and how many rows that is
     unsigned int next_entry[5]; // k_wave_pairs: work-list entries handed out beyond the first static round
-    unsigned int bins_total16;  // binned mode (strsim_bins.h): 16-byte units the frame's bins take (what the next call's buffer is sized by) ...
-    unsigned int bins_rows;     // ... and the rows that went to them (0: not binned)
-    unsigned int pad1[10];
+    unsigned int pad1[12];
     unsigned int ticket;    // host-mapped copy only: the call's ticket, written LAST (release, system scope) by whoever publishes
                             // the block -- strsim_ctx_retire_oldest() refuses a slot whose ticket has not arrived
 };
@@ -73,20 +71,7 @@ struct LaunchArgs {
     int wave_grid_lev;            // k_wave_pairs<LEVENSHTEIN> (LDS-light: more waves per CU)
     uint32_t *lev_ws;             // its global scratch: wave_grid_lev * LEV_WS_WORDS words
     hipEvent_t ev_lane0, ev_lane1, ev_wave1; // optional (nullptr = no timing)
-    // binned mode (strsim_bins.h; single-measure calls of two columns on a context whose last call left many rows of 33..128
-    // bytes): the rows k_lane_stage does not finish go to k_wide_bins through pages in bins_buf
-    bool use_bins;
-    int num_cu;
-    uint8_t *bins_buf;            // bins_cap16 * 16 bytes
-    uint32_t bins_cap16;
-    void *bin_table;              // device BinTable
-    uint32_t *bin_hist;           // groups x 256 words: per-group counts, then the groups' first positions
-    uint32_t *bin_seg;            // segments x 256 words
 };
-// scratch of the binned mode for a call of n rows: words of bin_hist / bin_seg, bytes of the table
-size_t bin_hist_words(uint64_t n);
-size_t bin_seg_words(uint64_t n);
-size_t bin_table_bytes();
 
 hipError_t launch_pairs(int measure, const LaunchArgs &a);
 // the two halves of launch_pairs for a call that looks at lane_left in between (small calls: usually nothing is left)

@@ -34,11 +34,9 @@
 #include "strsim_lane_core.h"
 #include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
-#include "strsim_lane_wide_lut.h"
 #include "strsim_lane_sym.h"
 #include "strsim_kernels.h"
 #include "strsim_lane_common.h"
-#include "strsim_bins.h"
 
 namespace strsim {
 
@@ -339,8 +337,6 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
       lds_barrier();
     }
 }
-
-#include "strsim_lane_bins.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_utf8: one pair per lane for short NON-ASCII strings -- both strings <= 128 bytes and, once decoded,
@@ -1991,21 +1987,6 @@ static void launch_lane_t(const LaunchArgs &a)
                            litA ? a.valB : a.valA, litA ? a.offA : a.offB, litA ? a.valA : a.valB, a.out, a.n, a.slowmask,
                            a.status, a.qtab, a.sched);
         if (a.publish_host) hipLaunchKernelGGL(k_publish_lit, dim3(1), dim3(64), 0, a.stream, a.sched, a.publish_host, a.publish_ticket);
-    } else if (a.use_bins) {
-        // binned mode (strsim_bins.h): lay the bins out from the lengths, then the staged kernel that fills them
-        constexpr bool SYMMETRIC = M == LEVENSHTEIN || M == JACCARD || M == SORENSEN_DICE;
-        const uint64_t ngroups = (a.n + BIN_GROUP_ROWS - 1) / BIN_GROUP_ROWS, nseg = (ngroups + BIN_SEG_GROUPS - 1) / BIN_SEG_GROUPS;
-        BinTable *const table = static_cast<BinTable *>(a.bin_table);
-        hipLaunchKernelGGL((k_bin_hist<SYMMETRIC>), dim3((unsigned)nseg), dim3(256), 0, a.stream, a.offA, a.offB, a.n, a.bin_hist, a.bin_seg);
-        hipLaunchKernelGGL(k_bin_top, dim3(1), dim3(256), 0, a.stream, a.bin_seg, (uint32_t)nseg, table, a.bins_cap16, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_bin_base, dim3((unsigned)nseg), dim3(256), 0, a.stream, a.bin_hist, a.bin_seg, ngroups);
-        const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
-        const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M, false>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
-        uint64_t gs = stage_launch_size(nsb, res, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
-        if (gs > ngroups) gs = ngroups; // (a workgroup's unit is a group)
-        hipLaunchKernelGGL((k_lane_stage_bins<M>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
-                           a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket,
-                           BinArgs{a.bin_hist, table, reinterpret_cast<uint4 *>(a.bins_buf)});
     } else {
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
@@ -2026,37 +2007,6 @@ static void launch_lane_t(const LaunchArgs &a)
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
 }
 
-// k_wide_bins, one launch per mask width: as many waves as are resident (they walk the class's pages in turn; a class without
-// pages costs its waves one load).
-template <int M, int W, bool LUT>
-static unsigned wide_bins_grid(int num_cu)
-{
-    static int per_cu = 0; // (one device kind per process; the query needs the current device, which the caller has set)
-    if (per_cu == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wide_bins<M, W, LUT>, 64, 0) != hipSuccess || n < 1) {
-            (void)hipGetLastError();
-            n = 4 * WideBinsGeom<M, W, LUT>::WAVES_PER_EU;
-        }
-        per_cu = n;
-    }
-    return (unsigned)(per_cu * num_cu);
-}
-template <int M>
-static void launch_wide_bins(const LaunchArgs &a, double *out)
-{
-    const BinTable *const table = static_cast<const BinTable *>(a.bin_table);
-    const uint4 *const recs = reinterpret_cast<const uint4 *>(a.bins_buf);
-    static const bool lut = [] { const char *e = getenv("STRSIM_BINS_LUT"); return e ? atoi(e) != 0 : true; }(); // (A/B knob)
-    auto go = [&](auto use_lut) {
-        constexpr bool L = decltype(use_lut)::value;
-        hipLaunchKernelGGL((k_wide_bins<M, 4, L>), dim3(wide_bins_grid<M, 4, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
-        hipLaunchKernelGGL((k_wide_bins<M, 3, L>), dim3(wide_bins_grid<M, 3, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
-        hipLaunchKernelGGL((k_wide_bins<M, 2, L>), dim3(wide_bins_grid<M, 2, L>(a.num_cu)), dim3(64), 0, a.stream, table, recs, a.offA, a.valA, a.rowsA, a.offB, a.valB, a.rowsB, out, a.slowmask);
-    };
-    if (lut) go(std::true_type{}); else go(std::false_type{});
-}
-
 template <int M>
 static void launch_slow_t(const LaunchArgs &a)
 {
@@ -2065,7 +2015,6 @@ static void launch_slow_t(const LaunchArgs &a)
     const uint64_t wg = M == LEVENSHTEIN ? (uint64_t)a.wave_grid_lev
                         : (M == JARO || M == JARO_WINKLER) ? (uint64_t)a.wave_grid * 3u / 4u : (uint64_t)a.wave_grid;
     const uint64_t g2 = nchunks < wg ? nchunks : wg;
-    if (a.use_bins) launch_wide_bins<M>(a, a.out);
     {
         uint32_t sps, sps8;
         unsigned g3, g8;
@@ -2190,18 +2139,9 @@ int wave_lev_resident_per_cu()
     return n;
 }
 
-size_t bin_hist_words(uint64_t n) { return (size_t)((n + BIN_GROUP_ROWS - 1) / BIN_GROUP_ROWS) * BIN_COUNT; }
-size_t bin_seg_words(uint64_t n)
-{
-    const uint64_t ngroups = (n + BIN_GROUP_ROWS - 1) / BIN_GROUP_ROWS;
-    return (size_t)((ngroups + BIN_SEG_GROUPS - 1) / BIN_SEG_GROUPS) * BIN_COUNT;
-}
-size_t bin_table_bytes() { return sizeof(BinTable); }
-
 int lane_kernel_launches(int measure, const LaunchArgs &a)
 {
     if (measure == 5) return 1;
-    if (a.use_bins) return 4; // k_bin_hist, k_bin_top, k_bin_base, k_lane_stage_bins
     const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
     const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
     return (lit_path && !a.no_literal_path) ? 2 : 1; // k_lane_lit + k_publish_lit

@@ -35,9 +35,6 @@
 #ifndef STRSIM_STAGE_CAP_LUT
 #define STRSIM_STAGE_CAP_LUT 8960 // the same for the instantiations with match-mask tables (40 KB of LDS: four workgroups per CU)
 #endif
-#ifndef STRSIM_STAGE_CAP_BINS
-#define STRSIM_STAGE_CAP_BINS 8608 // the same in binned mode (4 KB of LDS for the bins' cursors, positions and bases: still five workgroups per CU)
-#endif
 #ifndef STRSIM_STAGE_WAVES_PER_EU
 #define STRSIM_STAGE_WAVES_PER_EU 5
 #endif
@@ -85,8 +82,8 @@ constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and blo
 template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_LUT >> MEASURE) & 1) != 0; } // (5: five outputs)
 
 // staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
-template <bool TABLES, bool BINS = false> struct StageGeom {
-    static constexpr int CAP = TABLES ? STRSIM_STAGE_CAP_LUT : (BINS ? STRSIM_STAGE_CAP_BINS : STRSIM_STAGE_CAP);
+template <bool TABLES> struct StageGeom {
+    static constexpr int CAP = TABLES ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP;
     static constexpr int COL = CAP + 96;              // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
     static constexpr int DMA_ITERS = (CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
     static_assert(CAP % 16 == 0 && 2 * COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
@@ -135,12 +132,6 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // "text" is the string the columns of the bit-parallel cores walk: a, or the shorter one for the symmetric measures
 // when both sides are columns.
 constexpr uint32_t STAGE_DEAD = 1u << 31;
-// binned mode, rows this kernel hands over (lengths up to 128: 8 bits each): a candidate for the bins; one whose strings do not lie
-// inside the staging area (a chunk that alone overflows it: the descriptor's 16-bit addresses cannot say where they are): its
-// record is marked dead and the row stays in the mask
-constexpr uint32_t STAGE_CAND = 1u << 30, STAGE_NOCOPY = 1u << 29;
-constexpr uint32_t STAGE_BINNED16 = 0xFFFEu, STAGE_BINNED32 = 0xFFFFFFFEu; // staged "result" of a row that went to the bins
-
 
 // 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7]: nine dwords from the dword-aligned address below (56 LDS
 // cycles per 64 lanes) + eight v_alignbyte_b32.  (gfx950 serves a wide LDS read that is not naturally aligned one lane at a time:
@@ -318,28 +309,19 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
     }
 }
 
-// BINS: the rows of 33..128 bytes this kernel does not finish are handed over to k_wide_bins (strsim_bins.h): copied out of the
-// staging area into the page slot their bin reserved for them.  Ranges are then whole groups of BIN_GROUP_ROWS rows, whose first
-// position in every bin bins.base holds.
-template <int MEASURE, bool LUT, bool BINS>
+template <int MEASURE, bool LUT>
 __device__ __forceinline__ void
 lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs,
              uint64_t n, unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status,
-             const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket,
-             const BinArgs bins)
+             const double *__restrict__ qtab, uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
-    // the rows this kernel does not compute sort behind its own (key NBK - 1); in binned mode the candidates for the bins come first
-    // among them (key NBK - 1) and the rest gets a key of its own (NBK)
-    constexpr int DEADKEY = BINS ? NBK : NBK - 1;
-    static_assert(DEADKEY < 32, "the bucket scan runs on 32 lanes");
-    static_assert(!BINS || MEASURE != ALL_MEASURES, "the five-output pass is not binned");
-    constexpr int STAGE_CAP = StageGeom<LUT, BINS>::CAP, STAGE_COL = StageGeom<LUT, BINS>::COL;
-    constexpr int STAGE_DMA_ITERS = StageGeom<LUT, BINS>::DMA_ITERS;
+    constexpr int STAGE_CAP = StageGeom<LUT>::CAP, STAGE_COL = StageGeom<LUT>::COL;
+    constexpr int STAGE_DMA_ITERS = StageGeom<LUT>::DMA_ITERS;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
@@ -358,24 +340,13 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     __shared__ uint32_t s_sched[2];            // the next range of 64-row chunks of this workgroup: first chunk, chunks
     // results wait in LDS for the coalesced store phase as the integers their f64 epilogue needs (all-ones = the row was not
     // computed here): Levenshtein a 16-bit table index, the other measures 32 bits, the five-output pass 64
-    __shared__ uint32_t s_cur[BINS ? BIN_COUNT : 1]; // binned mode: the next free position of every bin within the current group
-    __shared__ uint32_t s_pos[BINS ? B : 1];         // ... and the position each candidate of the block has taken (by place in the sort order)
-    __shared__ uint32_t s_base16[BINS ? BIN_COUNT : 1]; // ... where every bin's pages start (BinTable::base16)
     __shared__ uint16_t s_code[LEV ? B : 1];
     __shared__ uint32_t s_word[(!LEV && !ALL) ? B : 1];
     __shared__ double s_val[ALL ? B : 1];
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     // the call's status block (counters of the kernels that follow in the stream) is cleared here, not by a memset node
-    static_assert(!BINS || STAGE_BLOCK == BIN_COUNT, "binned mode: one thread per bin");
-    // binned mode: is the frame binned at all (k_bin_top: does the buffer hold it)?  (uniform)
-    const bool bins_on = BINS && load_invariant(&bins.table->enabled) != 0u;
-    if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) {
-        uint32_t v = 0u; // (binned mode: what the host sizes the next call's buffer and its choice of path by)
-        if (BINS && tid == (uint32_t)(offsetof(DevStatus, bins_total16) / 4)) v = bins.table->total16;
-        if (BINS && tid == (uint32_t)(offsetof(DevStatus, bins_rows) / 4)) v = bins_on ? bins.table->rows : 0u;
-        reinterpret_cast<uint32_t *>(status)[tid] = v;
-    }
+    if (blockIdx.x == 0u && tid < (uint32_t)(sizeof(DevStatus) / sizeof(uint32_t))) reinterpret_cast<uint32_t *>(status)[tid] = 0u;
     if (tid < 32u) s_cnt[tid] = 0u;
     if (tid == 0u) s_left = 0u;
 #pragma unroll
@@ -417,11 +388,6 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     const uint64_t nchunks = (n + 63u) >> 6;
     const uint32_t nchunks32 = (uint32_t)nchunks; // (at most 2^32 - 1 rows per call)
     auto grab = [&](uint32_t seen, uint32_t &lo, uint32_t &sz) { // thread 0 only
-        if (BINS) { // whole groups: a group's positions in the bins are known per group
-            sz = (uint32_t)BIN_GROUP_CHUNKS;
-            lo = __hip_atomic_fetch_add(&sched[0], sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
         // (64 * 4 * workgroups chunks left or more: the cap; no division on this path)
         const uint32_t left = nchunks32 > seen ? nchunks32 - seen : 0u;
         uint32_t want = (uint32_t)STRSIM_STAGE_RANGE_MAX;
@@ -446,11 +412,6 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     lds_barrier();
     if (tid == 0u) grab(grab_lo, grab_lo, grab_sz); // (written to s_sched at the top of the first block)
     bool grab_pending = true;
-    // binned mode: where the group's rows go in every bin (thread b: bin b); published by the barrier in front of the first block
-    if (BINS) s_base16[tid] = bins_on ? bins.table->base16[tid] : 0u;
-    if (BINS) s_cur[tid] = (bins_on && row0 < row_end) ? bins.base[(row0 / (uint64_t)BIN_GROUP_ROWS) * (uint64_t)BIN_COUNT + tid] : 0u;
-    uint32_t cur_next = 0u;  // ... of the group after this one, on its way (loaded when the range is switched, stored behind the rounds)
-    bool cur_load = false;
 
     EqLut lut; // this wave's match-mask tables
     lut.lane4 = lane * 4u;
@@ -516,7 +477,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
                 // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
                 // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
-                t0[q] = qtab[(uint32_t)pk[q] >= (BINS ? STAGE_BINNED16 : 0xFFFFu) ? 0u : (uint32_t)pk[q]];
+                t0[q] = qtab[(uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q]];
             } else if (JARO_LIKE) {
                 const uint32_t lo = (uint32_t)pk[q], hi = (uint32_t)(pk[q] >> 32);
                 const uint32_t m = (lo >> (ALL ? 6 : 0)) & 63u, t = (lo >> (ALL ? 12 : 6)) & 63u;
@@ -544,22 +505,19 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             if ((uint32_t)q * STAGE_BLOCK < rows) { // (uniform)
                 bool undone;
                 double v = 0.0, v5[5];
-                bool binned = false; // (binned mode) the row went to k_wide_bins: nothing to store, nothing left in the mask
                 if (ALL) {
                     undone = pk[q] == ~0ull;
                     if (!undone) stage_all_epilogues(pk[q], t0[q], t1[q], t2[q], t3[q], v5);
                 } else if (LEV) {
                     undone = (uint32_t)pk[q] == 0xFFFFu;
-                    binned = BINS && (uint32_t)pk[q] == STAGE_BINNED16;
                     v = 1.0 - t0[q];
                 } else {
                     undone = (uint32_t)pk[q] == 0xFFFFFFFFu;
-                    binned = BINS && (uint32_t)pk[q] == STAGE_BINNED32;
                     if (!undone) v = stage_epilogue<M1>((uint32_t)pk[q], t0[q], t1[q], t2[q]);
                 }
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
-                if (valid && !undone && !binned) {
+                if (valid && !undone) {
                     if (ALL) {
 #pragma unroll
                         for (int o = 0; o < 5; ++o) outs.p[o][r0 + i] = v5[o];
@@ -637,7 +595,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         }
         STAGE_STAMP(0);
         // ---- C: sortA(j): lengths -> bucket keys (number of DP columns the pair will run), ranks by LDS atomics
-        uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT], spos[BINS ? RPT : 1];
+        uint32_t skey[RPT], srank[RPT], sd0[RPT], sd1[RPT];
         {
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
@@ -652,23 +610,18 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t wa = bcastA ? LIT : misA + a0, wb = bcastB ? LIT + 32u : COLB + misB + b0;
                 const bool swap = SYMMETRIC && !bcastA && !bcastB && la8 > lb8; // symmetric measures walk the shorter string
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
-                // binned mode: a row of 33..128 bytes takes the next position of its bin (every candidate does, copied or not:
-                // the bin's slots were counted by the lengths alone)
-                const bool cand = BINS && bins_on && have && !mine && bin_candidate(la8, lb8);
-                const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(cand ? NBK - 1 : DEADKEY);
+                const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
                 skey[q] = key;
                 srank[q] = atomicAdd(&s_cnt[key], 1u);
-                if (BINS) spos[q] = cand ? atomicAdd(&s_cur[bin_of(lt, lp)], 1u) : 0u;
-                sd0[q] = (mine || cand) ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
-                sd1[q] = mine ? (lt | (lp << 8) | (i << 16))
-                         : cand ? (lt | (lp << 8) | (i << 16) | STAGE_DEAD | STAGE_CAND | ((stA && stB) ? 0u : STAGE_NOCOPY)) : STAGE_DEAD;
+                sd0[q] = mine ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
+                sd1[q] = mine ? (lt | (lp << 8) | (i << 16)) : STAGE_DEAD;
             }
         }
         STAGE_STAMP(2);
         lds_barrier();
         STAGE_STAMP(3);
         // ---- C: sortB(j): exclusive scan of the bucket counters (every wave for itself), descriptors in length order
-        uint32_t nmine, ncand = 0u;
+        uint32_t nmine;
         {
             const uint32_t c = s_cnt[lane & 31u];
             const uint32_t exc = scan32_inclusive(c) - c;
@@ -677,10 +630,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t base = __shfl(exc, skey[q], 32);
                 const uint32_t p = base + srank[q]; // position in length order
                 *desc_at(p) = make_uint2(sd0[q], sd1[q]);
-                if (BINS) s_pos[p] = spos[q];
             }
             nmine = uniform(__shfl(exc, NBK - 1, 32));
-            if (BINS) ncand = uniform(__shfl(c, NBK - 1, 32));
         }
         STAGE_STAMP(4);
         // ---- D: the bytes have landed (every wave waits for its own DMA, the barrier makes that workgroup-wide)
@@ -703,36 +654,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             row_end = hi * 64u < n ? hi * 64u : n;
             if (tid == 0u) grab((uint32_t)lo, grab_lo, grab_sz);
             grab_pending = true;
-            if (BINS) { // the next group's first positions (this block's candidates took theirs in sortA, in front of barrier D)
-                cur_next = (bins_on && next_row0 < row_end) ? bins.base[(next_row0 / (uint64_t)BIN_GROUP_ROWS) * (uint64_t)BIN_COUNT + tid] : 0u;
-                cur_load = true;
-            }
         }
         if (next_row0 < row_end) dma_offsets(next_row0);
         STAGE_STAMP(6);
-        if constexpr (BINS) {
-            // ---- E': the block's candidates for the bins leave as RECORDS (strsim_bins.h): the row, where its text and its pattern
-            //          start in their columns, the two lengths within the bin's ranges -- one 16-byte store per row.
-            for (uint32_t p = nmine + tid; p < nmine + ncand; p += (uint32_t)STAGE_BLOCK) {
-                const uint2 d = *desc_at(p);
-                const uint32_t pos = s_pos[p];
-                const uint32_t lt = d.y & 0xFFu, lp = (d.y >> 8) & 0xFFu, idx = (d.y >> 16) & 0x1FFu;
-                const uint32_t bin = bin_of(lt, lp);
-                // the descriptor holds staging-area addresses: column a's area starts at 0, column b's at COLB
-                const uint32_t wt = d.x & 0xFFFFu, wp = d.x >> 16;
-                const bool t_in_b = wt >= COLB;
-                const uint32_t toff = t_in_b ? baseB - misB + (wt - COLB) : baseA - misA + wt;
-                const uint32_t poff = t_in_b ? baseA - misA + wp : baseB - misB + (wp - COLB);
-                const bool dead = (d.y & STAGE_NOCOPY) != 0u;
-                bins.buf[(size_t)s_base16[bin] + pos] =
-                    make_uint4(dead ? BIN_DEAD_ROW : (uint32_t)(row0 + idx), toff, poff, bin_len_byte(lt, lp) | (t_in_b ? BIN_REC_TEXT_IN_B : 0u));
-                if (!dead) {
-                    if (LEV) s_code[idx] = (uint16_t)STAGE_BINNED16;
-                    else s_word[idx] = STAGE_BINNED32;
-                }
-            }
-        }
-
         // ---- F: rounds(j): wave w runs rounds w, 2W-1-w, 2W+w, ... of the length order (short + long = balanced)
         __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
         {
@@ -755,12 +679,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 STAGE_STAMP(8);
             }
         }
-        __builtin_amdgcn_s_setprio(1);
-        if (BINS && cur_load) { // the next group's first positions (loaded in phase E)
-            s_cur[tid] = cur_next;
-            cur_load = false;
-        }
         // ---- G: the rounds are done: the staging area, the descriptors and the result codes change hands
+        __builtin_amdgcn_s_setprio(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         STAGE_STAMP(9);
@@ -826,19 +746,7 @@ k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA
              unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
              uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<MEASURE, TABLES, false>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket, BinArgs{});
-}
-
-// Binned mode (strsim_bins.h; frames with many rows of 33..128 bytes): without tables -- most of what the kernel does on such a
-// frame is staging and handing rows over.
-template <int MEASURE>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE, false>()))) void
-k_lane_stage_bins(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
-                  const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
-                  unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
-                  uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket, const BinArgs bins)
-{
-    lane_stage_body<MEASURE, false, true>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket, bins);
+    lane_stage_body<MEASURE, TABLES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }
 
 // The five-output instantiation keeps the matching state of three cores alive at once and stages 64 bits per row.
@@ -848,5 +756,5 @@ k_lane_stage_all(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ 
                  unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
                  uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>(), false>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket, BinArgs{});
+    lane_stage_body<ALL_MEASURES, stage_uses_lut<ALL_MEASURES>()>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }

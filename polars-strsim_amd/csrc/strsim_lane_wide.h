@@ -233,44 +233,6 @@ STRSIM_HD void eq_wide(const uint32_t (&P)[NP][W], const uint32_t (&valid)[W], u
     }
 }
 
-// Where a column's match mask comes from.  The cores below take a provider: `group(c4)` once per text dword (four characters:
-// whatever can be prepared for all four at once), `fetch(group, byte)` per character, as early as the walk below can issue it
-// (a column AHEAD of its use), and `mask(group, col, byte, Eq)` where the column runs.  EqFill: bit fills + three-input ops on
-// the planes -- nothing to fetch; EqTab (strsim_lane_wide_lut.h): two table entries out of the lane's LDS tables.
-template <int NP, int W>
-struct EqFill {
-    const uint32_t (&P)[NP][W];
-    const uint32_t (&valid)[W]; // positions that may match at all (all ones for Levenshtein, the pattern's length for the others)
-    struct Group { uint32_t c4; };
-    struct Col {};
-    STRSIM_HD Group group(uint32_t c4) const { return Group{c4}; }
-    STRSIM_HD Col fetch(const Group &, int) const { return Col{}; }
-    STRSIM_HD void mask(const Group &g, const Col &, int byte, uint32_t (&Eq)[W]) const { eq_wide<NP, W>(P, valid, g.c4, byte, Eq); }
-};
-
-// The walk over the text, software-pipelined against the latency of the LDS (what hides it on the GPU is issue distance, not
-// occupancy: these kernels run two or three waves per SIMD): the text dword of group g + 2 is on its way while group g runs --
-// so the table coordinates of group g + 1 are ready a group early -- and each column's table entries are fetched while the
-// column in front of it computes.  f(group, col, g, jj) is called for every column, in order.  ng4 >= 1.
-template <class Txt, class EqSrc, class F>
-STRSIM_HD void walk_text(const Txt &txt, uint32_t ng4, const EqSrc &eq, F &&f)
-{
-    typename EqSrc::Group gc = eq.group(txt(0));
-    typename EqSrc::Col cc = eq.fetch(gc, 0);
-    uint32_t c_nxt = ng4 > 1u ? txt(1) : 0u;
-    for (uint32_t g = 0; g < ng4; ++g) {
-        const typename EqSrc::Group gn = eq.group(c_nxt); // (behind the last group: the coordinates of character 0 -- never used)
-        c_nxt = g + 2u < ng4 ? txt(g + 2u) : 0u;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const typename EqSrc::Col cn = jj < 3 ? eq.fetch(gc, jj + 1) : eq.fetch(gn, 0);
-            f(gc, cc, g, jj);
-            cc = cn;
-        }
-        gc = gn;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Levenshtein, W-word Myers/Hyyro in the arrangement of lev_myers32_snap (strsim_lane_core.h): the pattern b is RIGHT-aligned
 // (bit j = b[j], planes of the window that starts at b; rows at and above lb belong to whatever follows b and never
@@ -279,16 +241,15 @@ STRSIM_HD void walk_text(const Txt &txt, uint32_t ng4, const EqSrc &eq, F &&f)
 // as they are, the ones from gfull on run each column under `column < la`.  The distance after exactly la columns is
 // la + popc(Pv) - popc(Mv) over the pattern's rows.  la, lb >= 1; ng4 = text dwords the wave walks (uniform).
 // ---------------------------------------------------------------------------------------------
-// `eq`: the match masks of the pattern with every position valid (EqFill / EqTab built with all-ones).
-template <int W, class Txt, class EqSrc>
-STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const EqSrc &eq, uint32_t lb)
+template <int NP, int W, class Txt>
+STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const uint32_t (&P)[NP][W], uint32_t lb)
 {
-    uint32_t Pv[W], Mv[W];
+    uint32_t all[W], Pv[W], Mv[W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) { Pv[w] = 0xFFFFFFFFu; Mv[w] = 0u; }
-    auto column = [&](const typename EqSrc::Group &grp, const typename EqSrc::Col &col, int jj) {
+    for (int w = 0; w < W; ++w) { all[w] = 0xFFFFFFFFu; Pv[w] = 0xFFFFFFFFu; Mv[w] = 0u; }
+    auto column = [&](uint32_t c4, int jj) {
         uint32_t Eq[W], X[W], S[W], D0[W], nX[W], HN2[W];
-        eq.mask(grp, col, jj, Eq);
+        eq_wide<NP, W>(P, all, c4, jj, Eq);
 #pragma unroll
         for (int w = 0; w < W; ++w) X[w] = Eq[w] & Pv[w];
         add_wide(X, Pv, S);
@@ -306,10 +267,18 @@ STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_
             Mv[w] = bitop3<0x50>(D0[w], D0[w], nX[w]);  // D0 & X
         }
     };
-    walk_text(txt, ng4, eq, [&](const typename EqSrc::Group &grp, const typename EqSrc::Col &col, uint32_t g, int jj) {
-        if (g < gfull) column(grp, col, jj);                        // (uniform) no lane's text ends in this group
-        else if (4u * g + (uint32_t)jj < la) column(grp, col, jj);
-    });
+    uint32_t g = 0;
+    for (; g < gfull && g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) column(c4, jj);
+    }
+    for (; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (4u * g + (uint32_t)jj < la) column(c4, jj);
+    }
     uint32_t rows[W];
     low_ones_wide<W>(lb, rows);
     uint32_t up = 0u, down = 0u;
@@ -330,9 +299,8 @@ STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_
 // moved).  Rounds 1-2 walked a again and rebuilt every column's match mask to test one bit of it: 9 + 9 W instructions
 // per column of a against about ten per position of b here, and the flags of a (kept in LDS between the passes) are gone.
 // ---------------------------------------------------------------------------------------------
-// `eq`: the match masks of the pattern, clamped to its length (EqFill / EqTab built with the pattern's length mask).
-template <int W, class Txt, class Sa, class EqSrc>
-STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, uint32_t nb4, const EqSrc &eq,
+template <int NP, int W, class Txt, class Sa>
+STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, uint32_t nb4, const uint32_t (&P)[NP][W],
                          const uint32_t (&wp)[8 * W], const Sa &sa, uint32_t &m_out, uint32_t &t_out)
 {
     // Instruction diet: the two window masks move along as carry chains (himask is not clamped to lb -- the
@@ -341,33 +309,37 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u;
-    uint32_t himask[W], lomask[W], fb[W];
+    uint32_t lbmask[W], himask[W], lomask[W], fb[W];
+    low_ones_wide<W>(lb, lbmask);
     low_ones_wide<W>(bound + 1u, himask); // ones at [0, i + bound]
 #pragma unroll
     for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
     uint32_t m = 0u;
     uint32_t left = la - 1u; // la - 1 - i: negative from column la on
-    walk_text(txt, ng4, eq, [&](const typename EqSrc::Group &grp, const typename EqSrc::Col &col, uint32_t g, int ii) {
-        const uint32_t i = 4u * g + (uint32_t)ii;
-        const uint32_t dead = sign_fill(left); // all ones once i >= la
-        left -= 1u;
-        uint32_t Eq[W], cand[W], d[W];
-        eq.mask(grp, col, ii, Eq);
+    for (uint32_t g = 0; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
-            cand[w] = bitop3<0x10>(inwin, fb[w], dead);                       // inwin & ~fb & ~dead
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t i = 4u * g + (uint32_t)ii;
+            const uint32_t dead = sign_fill(left); // all ones once i >= la
+            left -= 1u;
+            uint32_t Eq[W], cand[W], d[W];
+            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
+                cand[w] = bitop3<0x10>(inwin, fb[w], dead);                       // inwin & ~fb & ~dead
+            }
+            minus1_wide(cand, d);
+#pragma unroll
+            for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
+            const uint32_t hit = any_wide<W>(cand);
+            sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
+            m = add_nz(m, hit);
+            shl1_one(himask);
+            shl1_ge(lomask, i, bound);
         }
-        minus1_wide(cand, d);
-#pragma unroll
-        for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
-        const uint32_t hit = any_wide<W>(cand);
-        // (SA overwrites the text behind the walk: position m <= i lies in a dword the walk has read two groups ago)
-        sa.put(m, (grp.c4 >> (8 * ii)) & 0xFFu, hit);
-        m = add_nz(m, hit);
-        shl1_one(himask);
-        shl1_ge(lomask, i, bound);
-    });
+    }
     uint32_t t = 0u, k = 0u;
     unrolled_until<0, 8 * W>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -391,46 +363,33 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
 }
 
 // Multiset intersection size, W words (see multiset_isect32).
-template <int W, class Txt, class EqSrc>
-STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, const EqSrc &eq)
+template <int NP, int W, class Txt>
+STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W])
 {
-    uint32_t used[W];
+    uint32_t lbmask[W], used[W];
+    low_ones_wide<W>(lb, lbmask);
 #pragma unroll
     for (int w = 0; w < W; ++w) used[w] = 0u;
     uint32_t left = la - 1u; // la - 1 - i: negative from column la on
-    walk_text(txt, ng4, eq, [&](const typename EqSrc::Group &grp, const typename EqSrc::Col &col, uint32_t, int ii) {
-        const uint32_t dead = sign_fill(left);
-        left -= 1u;
-        uint32_t Eq[W], cand[W], d[W];
-        eq.mask(grp, col, ii, Eq);
+    for (uint32_t g = 0; g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
 #pragma unroll
-        for (int w = 0; w < W; ++w) cand[w] = bitop3<0x10>(Eq[w], used[w], dead); // Eq & ~used & ~dead
-        minus1_wide(cand, d);
+        for (int ii = 0; ii < 4; ++ii) {
+            const uint32_t dead = sign_fill(left);
+            left -= 1u;
+            uint32_t Eq[W], cand[W], d[W];
+            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
 #pragma unroll
-        for (int w = 0; w < W; ++w) used[w] = bitop3<0xF4>(used[w], cand[w], d[w]); // used | lowest candidate
-    });
+            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x10>(Eq[w], used[w], dead); // Eq & ~used & ~dead
+            minus1_wide(cand, d);
+#pragma unroll
+            for (int w = 0; w < W; ++w) used[w] = bitop3<0xF4>(used[w], cand[w], d[w]); // used | lowest candidate
+        }
+    }
     uint32_t n = 0u;
 #pragma unroll
     for (int w = 0; w < W; ++w) n += popc32(used[w]);
     return n;
-}
-
-// the measure from a mask provider: eq built with all positions valid for Levenshtein, with the pattern's length mask otherwise
-template <int MEASURE, int W, class Txt, class Sa, class EqSrc>
-STRSIM_HD double lane_wide_from(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const EqSrc &eq, const uint32_t (&wp)[8 * W],
-                                uint32_t lb, uint32_t nb4, uint32_t a0w, uint32_t b0w, const Sa &sa)
-{
-    if (MEASURE == LEVENSHTEIN) {
-        return epilogue_levenshtein(lev_wide<W>(txt, la, gfull, ng4, eq, lb), la, lb);
-    } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
-        uint32_t m, t;
-        jaro_wide<W>(txt, la, ng4, lb, nb4, eq, wp, sa, m, t);
-        const double j = epilogue_jaro(m, t, la, lb);
-        return MEASURE == JARO ? j : epilogue_jaro_winkler(j, common_prefix4(a0w, la, b0w, lb));
-    } else {
-        const uint32_t isect = isect_wide<W>(txt, la, ng4, eq);
-        return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,11 +402,19 @@ template <int MEASURE, int NP, int W, class Txt, class Sa>
 STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, const uint32_t (&wp)[8 * W], uint32_t lb,
                                   uint32_t nb4, uint32_t a0w, uint32_t b0w, const Sa &sa)
 {
-    uint32_t P[NP][W], valid[W];
+    uint32_t P[NP][W];
     build_planes_wide<NP, W>(wp, P);
-    low_ones_wide<W>(MEASURE == LEVENSHTEIN ? 32u * W : lb, valid);
-    const EqFill<NP, W> eq{P, valid};
-    return lane_wide_from<MEASURE, W>(txt, la, gfull, ng4, eq, wp, lb, nb4, a0w, b0w, sa);
+    if (MEASURE == LEVENSHTEIN) {
+        return epilogue_levenshtein(lev_wide<NP, W>(txt, la, gfull, ng4, P, lb), la, lb);
+    } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
+        uint32_t m, t;
+        jaro_wide<NP, W>(txt, la, ng4, lb, nb4, P, wp, sa, m, t);
+        const double j = epilogue_jaro(m, t, la, lb);
+        return MEASURE == JARO ? j : epilogue_jaro_winkler(j, common_prefix4(a0w, la, b0w, lb));
+    } else {
+        const uint32_t isect = isect_wide<NP, W>(txt, la, ng4, lb, P);
+        return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
+    }
 }
 
 } // namespace strsim

@@ -125,8 +125,6 @@ def lib():
     L.strsim_ctx_last_wave_rows.argtypes = [vp]
     L.strsim_ctx_last_long_rows.restype = u64
     L.strsim_ctx_last_long_rows.argtypes = [vp]
-    L.strsim_ctx_last_binned_rows.restype = u64
-    L.strsim_ctx_last_binned_rows.argtypes = [vp]
     L.strsim_ctx_last_late_rows.restype = u64
     L.strsim_ctx_last_late_rows.argtypes = [vp]
     L.strsim_codec_decode_gathered.restype = i32

@@ -79,11 +79,6 @@ class Context:
         return int(lib().strsim_ctx_last_wave_rows(self._h))
 
     @property
-    def last_binned_rows(self):
-        """Rows the last retired call handed to the binned kernels for strings of 33..128 bytes (0: the call was not binned)."""
-        return int(lib().strsim_ctx_last_binned_rows(self._h))
-
-    @property
     def last_late_rows(self):
         """Rows finished by a pass that the last synchronize() / retire_oldest() launched (slow rows of a one-launch call,
         long strings): written AFTER whatever was enqueued on the stream behind the call."""

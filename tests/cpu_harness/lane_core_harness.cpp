@@ -7,7 +7,6 @@
 #include "strsim_lane_core.h"
 #include "strsim_lane_lut.h"
 #include "strsim_lane_wide.h"
-#include "strsim_lane_wide_lut.h"
 #include "strsim_lane_sym.h"
 #include "lane_core_textbook.h"
 
@@ -167,10 +166,8 @@ struct ArrSa {
     uint32_t get(uint32_t k) const { return bytes[k]; }
 };
 
-// The text may be longer than the masks are wide (the binned kernel sizes the masks by the PATTERN: Jaro's a can have 128 bytes
-// against a b of 40): 32 dwords of text whatever W is.  lut != 0: match masks from tables (strsim_lane_wide_lut.h).
 template <int M, int NP, int W>
-static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w, int lut)
+static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w)
 {
     const uint32_t ng4 = (la + 3u) / 4u;
     // (nb4: any value from ceil(lb / 4) up to the window: the kernel passes the wave's maximum)
@@ -178,20 +175,13 @@ static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W]
     const uint32_t a0w = ta[0];
     // (gfull: any value up to la / 4; the kernel passes the wave's minimum -- sweep it through a few)
     const uint32_t gfull = (la / 4u) * ((la ^ lb) & 3u) / 3u;
-    if (lut) {
-        if constexpr (W >= 2 && NP != 6) {
-            WideLut<W> t{};
-            return lane_wide_result_lut<M, NP, W>(t, ArrTxt{ta}, la, gfull, ng4, wp, lb, nb4, a0w, b0w, ArrSa{reinterpret_cast<uint8_t *>(ta)});
-        }
-        return -1.0;
-    }
     return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, nb4, a0w, b0w, ArrSa{reinterpret_cast<uint8_t *>(ta)});
 }
 
 template <int M, int W>
-static double run_wide(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill, int lut)
+static double run_wide(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
 {
-    uint32_t ta[32], wp[8 * W], wbn[8 * W];
+    uint32_t ta[8 * W], wp[8 * W], wbn[8 * W];
     uint8_t buf[32 * W];
     std::memset(ta, fill, sizeof ta);
     std::memcpy(ta, a, la);
@@ -201,45 +191,37 @@ static double run_wide(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t
     std::memcpy(wp, buf, sizeof buf);
     // varying bits over both windows
     uint32_t o = 0, n = 0xFFFFFFFFu;
-    for (int d = 0; d < 32; ++d) { o |= ta[d]; n &= ta[d]; }
-    for (int d = 0; d < 8 * W; ++d) { o |= wp[d]; n &= wp[d]; }
+    for (int d = 0; d < 8 * W; ++d) { o |= ta[d] | wp[d]; n &= ta[d] & wp[d]; }
     uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
     uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
-    int np = force_np ? force_np : planes_needed((o8 ^ n8) & 0xFFu);
-    if (lut && np == 6) np = 7; // (the kernels have no six-plane instantiation either)
+    const int np = force_np ? force_np : planes_needed((o8 ^ n8) & 0xFFu);
     switch (np) {
-    case 5: return run_wide_np<M, 5, W>(ta, la, wp, lb, wbn[0], lut);
-    case 6: return run_wide_np<M, 6, W>(ta, la, wp, lb, wbn[0], lut);
-    default: return run_wide_np<M, 7, W>(ta, la, wp, lb, wbn[0], lut);
+    case 5: return run_wide_np<M, 5, W>(ta, la, wp, lb, wbn[0]);
+    case 6: return run_wide_np<M, 6, W>(ta, la, wp, lb, wbn[0]);
+    default: return run_wide_np<M, 7, W>(ta, la, wp, lb, wbn[0]);
     }
 }
 
 template <int W>
-static double run_wide_m(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill, int lut)
+static double run_wide_m(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
 {
     switch (measure) {
-    case LEVENSHTEIN: return run_wide<LEVENSHTEIN, W>(a, la, b, lb, force_np, fill, lut);
-    case JARO: return run_wide<JARO, W>(a, la, b, lb, force_np, fill, lut);
-    case JARO_WINKLER: return run_wide<JARO_WINKLER, W>(a, la, b, lb, force_np, fill, lut);
-    case JACCARD: return run_wide<JACCARD, W>(a, la, b, lb, force_np, fill, lut);
-    default: return run_wide<SORENSEN_DICE, W>(a, la, b, lb, force_np, fill, lut);
+    case LEVENSHTEIN: return run_wide<LEVENSHTEIN, W>(a, la, b, lb, force_np, fill);
+    case JARO: return run_wide<JARO, W>(a, la, b, lb, force_np, fill);
+    case JARO_WINKLER: return run_wide<JARO_WINKLER, W>(a, la, b, lb, force_np, fill);
+    case JACCARD: return run_wide<JACCARD, W>(a, la, b, lb, force_np, fill);
+    default: return run_wide<SORENSEN_DICE, W>(a, la, b, lb, force_np, fill);
     }
 }
 
-// a of 1..128 bytes, b of 1..32*W bytes; lut: 0 = bit fills, 1 = tables (W >= 2)
-extern "C" double harness_lane_pair_wide2(int measure, int W, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb,
-                                          int force_np, int fill, int lut)
-{
-    if (W == 1) return run_wide_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill, lut);
-    if (W == 2) return run_wide_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill, lut);
-    if (W == 3) return run_wide_m<3>(measure, a, la, b, lb, force_np, (uint8_t)fill, lut);
-    return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill, lut);
-}
 // strings of 1..32*W bytes each
 extern "C" double harness_lane_pair_wide(int measure, int W, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb,
                                          int force_np, int fill)
 {
-    return harness_lane_pair_wide2(measure, W, a, la, b, lb, force_np, fill, 0);
+    if (W == 1) return run_wide_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 2) return run_wide_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 3) return run_wide_m<3>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
 }
 
 // ---- symbol (non-ASCII) cores ----------------------------------------------------------------------

@@ -33,8 +33,6 @@ def harness():
     L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_wide.restype = C.c_double
     L.harness_lane_pair_wide.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
-    L.harness_lane_pair_wide2.restype = C.c_double
-    L.harness_lane_pair_wide2.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
     L.harness_lane_pair_sym.restype = C.c_double
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
     L.harness_lev_snap.restype = C.c_uint32
@@ -140,28 +138,6 @@ def test_wide_cores_random_bit_exact(harness, measure, W):
             for force, fill in ((0, alphabet[n % len(alphabet)]), (7, 0)):
                 got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, len(a), b, len(b), force, fill)
                 assert bits(got) == bits(exp), (measure, W, a, b, got, exp)
-
-
-@pytest.mark.parametrize("measure", O.MEASURES)
-@pytest.mark.parametrize("W", [2, 3, 4])
-def test_wide_cores_with_tables_and_long_texts(harness, measure, W):
-    """The mask width follows the PATTERN (the binned kernel's classes): texts of up to 128 bytes against patterns of up to 32 W,
-    match masks from bit fills and from the split tables (strsim_lane_wide_lut.h), five and seven planes."""
-    rng = random.Random(2000 + W)
-    symmetric = measure in ("levenshtein", "jaccard", "sorensen_dice")
-    for alphabet in (b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))):
-        for n in range(500):
-            lb = rng.randint(1, 32 * W)
-            la = rng.randint(1, lb if symmetric else 128)  # (the symmetric measures walk the shorter string)
-            a = bytes(rng.choice(alphabet) for _ in range(la))
-            r = rng.random()
-            b = a[:lb] if r < 0.1 else bytes((a[i] if i < la and rng.random() < 0.8 else rng.choice(alphabet)) for i in range(lb))
-            if symmetric and len(a) > len(b):
-                a, b = b, a
-            exp = O.pair(measure, a, b)
-            for force, fill, lut in ((0, alphabet[n % len(alphabet)], 0), (0, alphabet[n % len(alphabet)], 1), (7, 0, 1)):
-                got = harness.harness_lane_pair_wide2(O.MEASURE_ID[measure], W, a, len(a), b, len(b), force, fill, lut)
-                assert bits(got) == bits(exp), (measure, W, lut, force, a, b, got, exp)
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
