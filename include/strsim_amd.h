@@ -184,6 +184,19 @@ STRSIM_API int strsim_ctx_timing_read(strsim_ctx_t *ctx, double *lane_kernel_ms,
 #define STRSIM_OFFSETS_FROM_LENGTHS_MAX_ROWS 16843009u
 STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint64_t rows, uint32_t *offsets);
 
+/* A column from Utf8View slots, on the device (ABI 1.4; SURVEY 8 f1: the layout the reference iterates, strsim.rs:46-47).  `views`:
+ * rows Arrow Utf8View slots of 16 bytes each, 16-byte aligned, as the engine holds them -- a u32 length, then either the string
+ * itself (length <= 12) or its first four bytes, a u32 buffer index and a u32 offset -- with ONE thing changed by the host on the
+ * way: a slot whose string does not fit it (length > 12) carries in its last word the string's offset in `long_values`, the bytes
+ * of those strings as the host has shipped them (any order, gaps allowed; the buffer index is ignored).  A null slot is shipped as
+ * length 0.  Writes offsets[rows + 1] and the packed values (their size, the sum of the lengths, is the host's to know: it has
+ * seen every length) -- what strsim_pairs_device() takes.  Asynchronous on the context's stream, two launches; the packed size of
+ * one call must fit 32-bit offsets, at most 33 554 432 rows per call.  Reference counterpart: none (the reference reads the views
+ * in place); this is what lets a host with few cycles to spare -- the engine-parallel mode packs on the calling thread alone --
+ * hand a String column over with a streaming copy instead of a gather. */
+STRSIM_API int strsim_column_from_views(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values,
+                                        uint32_t *offsets, uint8_t *values);
+
 /* Close the gaps between up to STRSIM_COMPACT_MAX_SEGMENTS byte segments on the device, one launch on the context's stream:
  * dst[dst_off[k] .. + bytes[k]) = src[src_off[k] .. + bytes[k]) for k < nseg; src and dst are distinct device buffers, the three
  * arrays are host memory (read before the call returns).  For a host that packs a column's values with several threads in ONE

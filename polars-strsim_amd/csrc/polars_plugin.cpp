@@ -287,6 +287,70 @@ uint64_t pack_range_onepass(const Column &c, uint64_t r0, uint64_t r1, uint64_t 
     return pos - base;
 }
 
+// VIEW-NATIVE form (opt-in, see run_rows): rows [r0, r1) of a column of views leave as the VIEWS THEMSELVES -- 16 bytes
+// per row, a streaming copy; no gather for the strings that sit in their views (<= 12 bytes: three quarters of a column of names)
+// -- and the device makes the column layout (strsim_column_from_views).  A string that does not fit its view is appended to the thread's own
+// segment lng[base .. limit) and its view's last word becomes its offset there (the buffer index no longer matters); a null
+// slot leaves as the empty string.  Returns the packed size (the sum of the lengths) and the segment's fill in `long_end`, or
+// ~0 when the segment overflows (the caller sizes the slice's segments exactly and comes again).
+uint64_t views_range(const Column &c, uint64_t r0, uint64_t r1, View *vout, uint8_t *lng, uint64_t base, uint64_t limit, uint64_t &long_end,
+                     bool stream)
+{
+    uint64_t pos = base, total = 0;
+    for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        const ArrowArray *a = k.a;
+        const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
+        const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)a->length) - k.row0);
+        const View *v = static_cast<const View *>(a->buffers[1]) + a->offset;
+        const int64_t *sizes = a->n_buffers >= 4 ? static_cast<const int64_t *>(a->buffers[a->n_buffers - 1]) : nullptr;
+        const int64_t nvar = sizes ? a->n_buffers - 3 : a->n_buffers - 2; // variadic data buffers
+        for (int64_t i = i0; i < i1; ++i) {
+            __m128i w = _mm_loadu_si128(reinterpret_cast<const __m128i *>(v + i));
+            if (k.nulls && !bit_at(k.nulls, a->offset + i)) {
+                w = _mm_setzero_si128();
+            } else {
+                const uint32_t len = v[i].len;
+                total += len;
+                if (len > 12u) {
+                    uint32_t bi, bo;
+                    memcpy(&bi, v[i].rest + 4, 4);
+                    memcpy(&bo, v[i].rest + 8, 4);
+                    if ((int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+                    if (pos + len > limit) return ~0ull;
+                    memcpy(lng + pos, static_cast<const uint8_t *>(a->buffers[2 + bi]) + bo, len);
+                    View patched = v[i];
+                    const uint32_t at = (uint32_t)pos; // (a segment lies below SLICE_BYTES < 2^32)
+                    memcpy(patched.rest + 8, &at, 4);
+                    w = _mm_loadu_si128(reinterpret_cast<const __m128i *>(&patched));
+                    pos += len;
+                }
+            }
+            if (stream) _mm_stream_si128(reinterpret_cast<__m128i *>(vout), w); // (the pinned staging is 16-byte aligned)
+            else _mm_storeu_si128(reinterpret_cast<__m128i *>(vout), w);
+            ++vout;
+        }
+    }
+    if (stream) _mm_sfence();
+    long_end = pos;
+    return total;
+}
+
+// bytes of the strings of rows [r0, r1) of a view column that do not fit their views
+uint64_t long_bytes(const Column &c, uint64_t r0, uint64_t r1)
+{
+    uint64_t bytes = 0;
+    for (size_t ci = r0 < r1 ? chunk_of(c, r0) : c.chunks.size(); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        const int64_t i0 = (int64_t)(std::max(r0, k.row0) - k.row0);
+        const int64_t i1 = (int64_t)(std::min(r1, k.row0 + (uint64_t)k.a->length) - k.row0);
+        const View *v = static_cast<const View *>(k.a->buffers[1]) + k.a->offset;
+        for (int64_t i = i0; i < i1; ++i)
+            if (v[i].len > 12u && (!k.nulls || bit_at(k.nulls, k.a->offset + i))) bytes += v[i].len;
+    }
+    return bytes;
+}
+
 // ---- input ownership -------------------------------------------------------------------------------
 struct InputGuard { // the callee owns the inputs: release every array, then every SeriesExport, exactly once
     SeriesExport *in;
@@ -596,14 +660,19 @@ struct Slot {
     uint64_t seg_src[2][32], seg_dst[2][32], seg_bytes[2][32];
     uint64_t span[2] = {0, 0}; // bytes of h_val[s] to ship (the last segment's end)
     Buf d_land[2];
+    // view-native slices (pack_slice_views): the views as they lie + the strings that do not fit them
+    bool as_views[2] = {false, false};
+    Buf h_views[2], d_views[2], h_long[2], d_long[2];
+    uint64_t long_span[2] = {0, 0}; // bytes of h_long[s] to ship
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
     bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
     hipEvent_t ev_kernels = nullptr, ev_results = nullptr; // behind the slice's kernels (compute stream) / its D2H (copy stream)
-    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; d_land[i].device = true; } d_out.device = true; }
+    Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; d_land[i].device = true; d_views[i].device = true; d_long[i].device = true; } d_out.device = true; }
     void release()
     {
-        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); d_land[i].release(); }
+        for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); d_land[i].release();
+                                      h_views[i].release(); d_views[i].release(); h_long[i].release(); d_long[i].release(); }
         h_out.release(); d_out.release();
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev_results) (void)hipEventDestroy(ev_results);
@@ -861,6 +930,69 @@ bool pack_slice_onepass(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &
     return true;
 }
 
+// Both view columns of a slice in the view-native form (views_range): thread t takes rows lo(t) .. lo(t+1) of each column, its long
+// strings go into its own segment of h_long[s] -- sized from lbpr256[s], the long bytes per row (x 256) the call's previous slice
+// had, plus slack; exactly (a pass over the lengths first) when that is not known yet or a segment overflows.  The segments need
+// no closing up: the views carry the offsets.  True on success; false when a column's packed values exceed SLICE_BYTES.
+bool pack_slice_views(const Column (&col)[2], uint64_t r0, uint64_t r1, Slot &sl, uint64_t (&lbpr256)[2], unsigned T)
+{
+    const uint64_t rows = r1 - r0;
+    T = (unsigned)std::min<uint64_t>(std::min<unsigned>(T, 32u), std::max<uint64_t>(rows / 16384, 1));
+    auto lo = [&](unsigned t) { return r0 + rows * t / T; };
+    bool exact = lbpr256[0] == ~0ull || lbpr256[1] == ~0ull;
+    for (;;) {
+        uint64_t base[2][33];
+        if (exact) {
+            uint64_t need[2][32];
+            fork_join(T, [&](unsigned t) { for (int s = 0; s < 2; ++s) need[s][t] = long_bytes(col[s], lo(t), lo(t + 1)); });
+            for (int s = 0; s < 2; ++s) {
+                base[s][0] = 0;
+                for (unsigned t = 0; t < T; ++t) base[s][t + 1] = base[s][t] + ((need[s][t] + 63) & ~(uint64_t)63);
+            }
+        } else {
+            for (int s = 0; s < 2; ++s) {
+                base[s][0] = 0;
+                for (unsigned t = 0; t < T; ++t) {
+                    const uint64_t n = lo(t + 1) - lo(t);
+                    const uint64_t cap = ((n * lbpr256[s]) >> 8) + (n >> 3) + 4096; // the estimate + 1/8 + 4 KB of slack
+                    base[s][t + 1] = base[s][t] + ((cap + 63) & ~(uint64_t)63);
+                }
+            }
+        }
+        for (int s = 0; s < 2; ++s) {
+            if (base[s][T] > SLICE_BYTES) return false;
+            sl.h_views[s].reserve(rows * sizeof(View) + 64);
+            sl.h_long[s].reserve(base[s][T] + 64);
+        }
+        uint64_t total[2][32], end[2][32];
+        fork_join(T, [&](unsigned t) {
+            for (int s = 0; s < 2; ++s)
+                total[s][t] = views_range(col[s], lo(t), lo(t + 1), static_cast<View *>(sl.h_views[s].p) + (lo(t) - r0),
+                                          static_cast<uint8_t *>(sl.h_long[s].p), base[s][t], base[s][t + 1], end[s][t], T >= 4u);
+        });
+        bool overflow = false;
+        for (int s = 0; s < 2; ++s)
+            for (unsigned t = 0; t < T; ++t) overflow = overflow || total[s][t] == ~0ull;
+        if (overflow) {
+            if (exact) fail("internal: a view-native segment overflowed its exact size");
+            exact = true; // (once: sized from the lengths themselves)
+            continue;
+        }
+        for (int s = 0; s < 2; ++s) {
+            uint64_t bytes = 0, lng = 0;
+            for (unsigned t = 0; t < T; ++t) { bytes += total[s][t]; lng += end[s][t] - base[s][t]; }
+            if (bytes > SLICE_BYTES) return false;
+            sl.bytes[s] = bytes;
+            sl.long_span[s] = end[s][T - 1];
+            sl.as_views[s] = true;
+            sl.lens8[s] = false;
+            sl.nseg[s] = 0;
+            lbpr256[s] = rows ? (lng * 256 + rows - 1) / rows : 0;
+        }
+        return true;
+    }
+}
+
 struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin call on stderr
     bool on;
     double t_pack = 0, t_copy = 0;
@@ -890,7 +1022,7 @@ struct PipeTimes { double t_launch = 0, t_wait = 0, t_d2h = 0; unsigned slices =
 // host copy.  (Reference: the row fan-out of strsim.rs:72-100; here the host has ONE packer, so the devices take turns
 // instead of shards -- a device's share of the packing threads would be a fraction of them.)
 void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t n, double *out, bool out_pinned, unsigned T,
-              bool direct_call, const std::vector<int> &devs, PhaseTimer &tm, std::vector<PipeTimes> &ptimes)
+              bool direct_call, bool engine_parallel, const std::vector<int> &devs, PhaseTimer &tm, std::vector<PipeTimes> &ptimes)
 {
     const size_t D = devs.size();
     ptimes.assign(D, PipeTimes{});
@@ -934,13 +1066,26 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
     const char *onepass_env = getenv("POLARS_STRSIM_ONE_PASS");
     const bool onepass_ok = lens8_ok && !lit[0] && !lit[1] && col[0].layout == L_VIEW && col[1].layout == L_VIEW &&
                             !(onepass_env && atoi(onepass_env) == 0);
+    // View-native slices: two view columns, not a small call; POLARS_STRSIM_VIEWS=1 switches them on.  OFF by
+    // default, by their own measurement (profiles/r4_f1_views.txt, 10 M rows, same box): a view is 16 bytes whatever the string --
+    // more than the packed form of a short string (cfg1: 9 bytes a row and column) -- so the streaming copy writes MORE than the
+    // gather it replaces and the link carries more: 9.3 vs 5.8 ms (cfg1) and 13.6 vs 8.6 ms (cfg2) with the packing pool, 61 vs 48
+    // and 101 vs 67 ms on the calling thread alone (the engine-parallel mode), with and without non-temporal stores.
+    (void)engine_parallel;
+    const char *views_env = getenv("POLARS_STRSIM_VIEWS");
+    const bool views_ok = !direct_call && !lit[0] && !lit[1] && col[0].layout == L_VIEW && col[1].layout == L_VIEW &&
+                          views_env && atoi(views_env) != 0;
+    uint64_t lbpr256[2] = {~0ull, ~0ull}; // long bytes per row (x 256) of the call's last slice: not known yet
     auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
         uint64_t rows = std::min<uint64_t>(want, n - r0);
         for (;;) {
             bool fits = true;
             sl.lens8[0] = sl.lens8[1] = false;
             sl.nseg[0] = sl.nseg[1] = 0;
-            if (onepass_ok && bpr256[0] && bpr256[1] && pack_slice_onepass(col, r0, r0 + rows, sl, bpr256, T)) {
+            sl.as_views[0] = sl.as_views[1] = false;
+            if (views_ok) {
+                fits = pack_slice_views(col, r0, r0 + rows, sl, lbpr256, T);
+            } else if (onepass_ok && bpr256[0] && bpr256[1] && pack_slice_onepass(col, r0, r0 + rows, sl, bpr256, T)) {
                 // (one pass: lengths + values in per-thread segments)
             } else if (!lit[0] && !lit[1]) {
                 fits = pack_slice2(col, r0, r0 + rows, sl, lens8_ok, T);
@@ -980,6 +1125,18 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
             }
             sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
             sl.d_val[s].reserve(sl.bytes[s] + 64);
+            if (sl.as_views[s]) { // the views as they lie + the long strings over the link, the column made on the device
+                sl.d_views[s].reserve(sl.rows * sizeof(View) + 64);
+                sl.d_long[s].reserve(sl.long_span[s] + 64);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_views[s].p, sl.h_views[s].p, sl.rows * sizeof(View), hipMemcpyHostToDevice, stream));
+                if (sl.long_span[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_long[s].p, sl.h_long[s].p, sl.long_span[s], hipMemcpyHostToDevice, stream));
+                if (strsim_column_from_views(ctx, sl.d_views[s].p, sl.rows, static_cast<const uint8_t *>(sl.d_long[s].p),
+                                             static_cast<uint32_t *>(sl.d_off[s].p), static_cast<uint8_t *>(sl.d_val[s].p)) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+                doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
+                dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
+                continue;
+            }
             if (sl.lens8[s]) { // lengths over the link, offsets rebuilt on the device
                 sl.d_len[s].reserve(sl.rows + 16);
                 HIP_OR_FAIL(hipMemcpyAsync(sl.d_len[s].p, sl.h_len[s].p, sl.rows, hipMemcpyHostToDevice, stream));
@@ -1220,7 +1377,7 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         const bool direct_call = n <= direct_rows();
         const uint64_t D = std::max<uint64_t>(1, std::min<uint64_t>(devs.size(), n / min_rows_per_device()));
         devs.resize((size_t)D);
-        run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, devs, tm, ptimes);
+        run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, engine_parallel, devs, tm, ptimes);
     }
 
     // output validity = AND of the input validities (broadcast for a literal; a null literal is the all_null case)
@@ -1382,6 +1539,47 @@ POLARS_PLUGIN_API int _strsim_test_pack_onepass(SeriesExport *series, uint64_t r
         // both "columns" are the same series: their segments must agree
         if (sl.bytes[1] != sl.bytes[0] || sl.nseg[1] != sl.nseg[0]) fail("the two columns of the slice disagree");
         return 1;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
+}
+
+// (1c) the VIEW-NATIVE form of one view Series used for both columns of a slice (pack_slice_views): rows [r0, r1) on `threads`
+// threads; lbpr256: the long bytes per row (x 256) to size the segments by, ~0: size them exactly.  Fills views_out (16 bytes per
+// row) and long_out (the segments as they lie, *span_out bytes) and *bytes_out (the packed size).  Returns 0 / -1.
+POLARS_PLUGIN_API int _strsim_test_pack_views(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t lbpr256, unsigned threads,
+                                              uint8_t *views_out, uint8_t *long_out, uint64_t long_cap, uint64_t *span_out, uint64_t *bytes_out)
+{
+    InputGuard guard{series, 1};
+    try {
+        Column col[2];
+        describe(*series, col[0]);
+        describe(*series, col[1]);
+        if (col[0].layout != L_VIEW) fail("view-native packing is for view columns");
+        if (r1 > col[0].rows) r1 = col[0].rows;
+        if (r0 > r1) r0 = r1;
+        Slot sl; // (plain memory stands in for the pinned staging: generous enough that reserve() never allocates -- no GPU here)
+        struct Free {
+            Slot &s;
+            ~Free() { for (int i = 0; i < 2; ++i) { free(s.h_views[i].p); free(s.h_long[i].p); s.h_views[i].p = s.h_long[i].p = nullptr; s.h_views[i].cap = s.h_long[i].cap = 0; } }
+        } fr{sl};
+        const uint64_t lcap = range_bytes(col[0], r0, r1) + (r1 - r0) + 64 * 4096 + 65536 + (((r1 - r0) * (lbpr256 == ~0ull ? 0 : lbpr256)) >> 7);
+        for (int i = 0; i < 2; ++i) {
+            sl.h_views[i].p = malloc((r1 - r0) * 16 + 128); sl.h_views[i].cap = (r1 - r0) * 16 + 128;
+            sl.h_long[i].p = malloc(lcap); sl.h_long[i].cap = lcap;
+        }
+        uint64_t l[2] = {lbpr256, lbpr256};
+        if (!pack_slice_views(col, r0, r1, sl, l, threads ? threads : 1)) fail("the slice exceeds the per-slice byte limit");
+        if (sl.long_span[0] > long_cap) fail("test buffer too small");
+        memcpy(views_out, sl.h_views[0].p, (r1 - r0) * 16);
+        memcpy(long_out, sl.h_long[0].p, sl.long_span[0]);
+        if (span_out) *span_out = sl.long_span[0];
+        if (bytes_out) *bytes_out = sl.bytes[0];
+        if (sl.bytes[1] != sl.bytes[0] || memcmp(sl.h_views[0].p, sl.h_views[1].p, (r1 - r0) * 16) != 0) fail("the two columns of the slice disagree");
+        return 0;
     } catch (const PluginError &e) {
         g_plugin_error = e.msg;
     } catch (...) {

@@ -330,6 +330,89 @@ __global__ __launch_bounds__(LEN_THREADS) void k_len_offsets(const uint8_t *__re
     for (uint32_t i = tid; i < cnt; i += LEN_THREADS) off[r0 + i + 1] = s_off[i];
 }
 
+// ---- a column from Utf8View slots (strsim_column_from_views) ------------------------------------------------------------
+// The engine holds a String column as 16-byte VIEWS (length; the string itself when it has at most 12 bytes, else its first four
+// bytes, a buffer index and an offset): the reference iterates them in place (strsim.rs:46-47).  A host that does not want to
+// gather the strings ships the views as they lie -- a streaming copy -- plus the bytes of the strings that do not fit their
+// view, and the column layout the kernels take (offsets + packed values) is made here: block sums of the lengths, then every
+// workgroup scans its rows and each thread writes its own row's bytes (consecutive lanes write consecutive bytes of `values`).
+constexpr int VIEW_THREADS = 256, VIEW_STRIPS = 8, VIEW_ROWS = VIEW_THREADS * VIEW_STRIPS;
+
+__global__ __launch_bounds__(VIEW_THREADS) void k_view_block_sums(const uint4 *__restrict__ views, uint64_t rows, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t s_part[VIEW_THREADS / 64];
+    const uint64_t r0 = (uint64_t)blockIdx.x * VIEW_ROWS;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < VIEW_STRIPS; ++k) {
+        const uint64_t r = r0 + (uint64_t)k * VIEW_THREADS + threadIdx.x;
+        if (r < rows) mine += reinterpret_cast<const uint32_t *>(views + r)[0];
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < VIEW_THREADS / 64; ++w) tot += s_part[w];
+        sums[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(VIEW_THREADS) void k_view_column(const uint4 *__restrict__ views, uint64_t rows, const uint8_t *__restrict__ longs,
+                                                             const uint32_t *__restrict__ sums, uint32_t *__restrict__ off,
+                                                             uint8_t *__restrict__ values)
+{
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    __shared__ uint32_t s_part[VIEW_THREADS / 64];
+    __shared__ uint32_t s_wave[VIEW_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * VIEW_ROWS;
+    // bytes in front of this block
+    uint32_t mine = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += VIEW_THREADS) mine += sums[b];
+    uint32_t run = block_sum(mine, s_part); // (block_sum is written for LEN_THREADS == VIEW_THREADS)
+    static_assert(VIEW_THREADS == LEN_THREADS, "block_sum");
+    if (blockIdx.x == 0 && tid == 0) off[0] = 0u;
+#pragma unroll 1
+    for (int k = 0; k < VIEW_STRIPS; ++k) {
+        const uint64_t r = r0 + (uint64_t)k * VIEW_THREADS + tid;
+        const uint4 v = r < rows ? views[r] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t len = v.x;
+        uint32_t inc = len;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += up;
+        }
+        if (lane == 63u) s_wave[wv] = inc;
+        __syncthreads();
+        uint32_t at = run + inc - len;
+        uint32_t strip = 0;
+        for (uint32_t w = 0; w < (uint32_t)(VIEW_THREADS / 64); ++w) {
+            if (w < wv) at += s_wave[w];
+            strip += s_wave[w];
+        }
+        __syncthreads();
+        run += strip;
+        if (r < rows) {
+            off[r + 1] = at + len;
+            uint8_t *__restrict__ const dst = values + at;
+            if (len <= 12u) { // the string is in the view: whole dwords, then the tail byte by byte
+                if (len >= 4u) *reinterpret_cast<u32_u *>(dst) = v.y;
+                if (len >= 8u) *reinterpret_cast<u32_u *>(dst + 4) = v.z;
+                if (len >= 12u) *reinterpret_cast<u32_u *>(dst + 8) = v.w;
+                const uint32_t tail = len & ~3u, word = tail == 0u ? v.y : (tail == 4u ? v.z : v.w);
+                for (uint32_t b = 0; b < (len & 3u); ++b) dst[tail + b] = (uint8_t)(word >> (8u * b));
+            } else { // ... in the bytes shipped beside the views, at offset v.w (the host has made it so)
+                const uint8_t *__restrict__ const src = longs + v.w;
+                uint32_t b = 0;
+                for (; b + 16u <= len; b += 16u) *reinterpret_cast<u32x4_u *>(dst + b) = *reinterpret_cast<const u32x4_u *>(src + b);
+                for (; b < len; ++b) dst[b] = src[b];
+            }
+        }
+    }
+}
+
 #define HIP_TRY(expr)                                          \
     do {                                                       \
         hipError_t e__ = (expr);                               \
@@ -501,6 +584,32 @@ int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint6
     if (rc) return rc;
     hipLaunchKernelGGL(k_len_block_sums, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums);
     hipLaunchKernelGGL(k_len_offsets, dim3((unsigned)nblk), dim3(LEN_THREADS), 0, st, lengths, rows, sums, offsets);
+    HIP_TRY(hipGetLastError());
+    return STRSIM_OK;
+}
+
+int strsim_column_from_views(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values, uint32_t *offsets,
+                             uint8_t *values)
+{
+    if (!ctx || !offsets || (rows && (!views || !values))) { set_error("strsim_column_from_views: NULL argument"); return STRSIM_ERR_ARG; }
+    const uint64_t nblk = (rows + VIEW_ROWS - 1) / VIEW_ROWS;
+    if (nblk > strsim::SCAN_WS_WORDS) {
+        set_error("strsim_column_from_views: %llu rows in one call; at most %llu", (unsigned long long)rows,
+                  (unsigned long long)(strsim::SCAN_WS_WORDS * (uint64_t)VIEW_ROWS));
+        return STRSIM_ERR_ARG;
+    }
+    if (reinterpret_cast<uintptr_t>(views) & 15u) { set_error("strsim_column_from_views: views must be 16-byte aligned"); return STRSIM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
+    if (rows == 0) {
+        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(uint32_t), st));
+        return STRSIM_OK;
+    }
+    uint32_t *sums = nullptr;
+    const int rc = strsim_internal_scan_workspace(ctx, &sums);
+    if (rc) return rc;
+    const uint4 *v = static_cast<const uint4 *>(views);
+    hipLaunchKernelGGL(k_view_block_sums, dim3((unsigned)nblk), dim3(VIEW_THREADS), 0, st, v, rows, sums);
+    hipLaunchKernelGGL(k_view_column, dim3((unsigned)nblk), dim3(VIEW_THREADS), 0, st, v, rows, long_values, sums, offsets, values);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

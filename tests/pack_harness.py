@@ -33,6 +33,9 @@ def lib():
         L._strsim_test_pack_onepass.restype = C.c_int
         L._strsim_test_pack_onepass.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p,
                                                 C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L._strsim_test_pack_views.restype = C.c_int
+        L._strsim_test_pack_views.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p,
+                                              C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L._polars_plugin_get_last_error_message.restype = C.c_char_p
         _lib = L
     return _lib
@@ -81,6 +84,36 @@ def pack_onepass(x, r0, r1, bytes_per_row, threads=1):
     if rc == 0:
         return None
     return lens[:n], val[: used.value], nseg.value
+
+
+def pack_views(x, r0, r1, threads=1, long_bytes_per_row=None):
+    """The view-native packer on a view column: -> (list of the rows' strings as bytes, rebuilt from the shipped views and the
+    long-string area the way the device does, packed size).  long_bytes_per_row None: the segments are sized exactly."""
+    L = lib()
+    chunks, dtype = H._chunks(x, "vu")
+    ex = H._Exported("col", chunks, dtype)
+    se = H.SeriesExport()
+    ex.fill(se)
+    n = r1 - r0
+    views = np.zeros((n + 8) * 16, dtype=np.uint8)
+    lng = np.zeros(n * 320 + (1 << 20), dtype=np.uint8)
+    span, total = C.c_uint64(), C.c_uint64()
+    est = 0xFFFFFFFFFFFFFFFF if long_bytes_per_row is None else int(long_bytes_per_row * 256)
+    rc = L._strsim_test_pack_views(C.byref(se), r0, r1, est, threads, views.ctypes.data, lng.ctypes.data, lng.size, C.byref(span),
+                                   C.byref(total))
+    assert ex.released == 1 and ex.arrays_released()
+    if rc != 0:
+        raise H.PluginError(L._polars_plugin_get_last_error_message().decode())
+    v = views[: n * 16].reshape(n, 16)
+    lens = v[:, :4].copy().view(np.uint32)[:, 0]
+    offs = v[:, 12:16].copy().view(np.uint32)[:, 0]
+    out = []
+    for i in range(n):
+        ln = int(lens[i])
+        out.append(bytes(v[i, 4:4 + ln]) if ln <= 12 else bytes(lng[int(offs[i]):int(offs[i]) + ln]))
+        if ln > 12:
+            assert int(offs[i]) + ln <= span.value
+    return out, total.value
 
 
 def validity(a, b, layouts=("vu", "vu"), threads=1, vals=None):

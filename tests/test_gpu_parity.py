@@ -834,3 +834,45 @@ def test_more_calls_in_flight_than_the_ring_holds(S):
         for o, k in zip(outs, order):
             assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "ring wrap, %d slow rows" % k)
         assert ctx.enqueued_ops >= len(order)
+
+
+def test_column_from_views(S, ctx):
+    """strsim_column_from_views: Utf8View slots as an engine holds them -- inline strings, strings in the
+    long-string area (any order, gaps between them), empty slots -- become offsets + packed values on the device."""
+    import random
+    import torch
+    rng = random.Random(77)
+    for n in (0, 1, 2047, 2048, 2049, 70_001):
+        rows = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz\xc3\xa9") for _ in range(rng.choice((0, 1, 3, 4, 7, 8, 11, 12, 13, 16, 17, 40, 255, 300))))
+                for _ in range(n)]
+        views = np.zeros((max(n, 1), 16), dtype=np.uint8)
+        longs = bytearray()
+        order = list(range(n))
+        rng.shuffle(order)  # the long strings lie in any order ...
+        at = {}
+        for i in order:
+            if len(rows[i]) > 12:
+                longs += b"\xff" * rng.randint(0, 5)  # ... with gaps
+                at[i] = len(longs)
+                longs += rows[i]
+        for i, r in enumerate(rows):
+            views[i, :4] = np.frombuffer(np.uint32(len(r)).tobytes(), dtype=np.uint8)
+            if len(r) <= 12:
+                views[i, 4:4 + len(r)] = np.frombuffer(r, dtype=np.uint8)
+            else:
+                views[i, 4:8] = np.frombuffer(r[:4], dtype=np.uint8)
+                views[i, 8:12] = 0xEE  # (the buffer index is not looked at)
+                views[i, 12:16] = np.frombuffer(np.uint32(at[i]).tobytes(), dtype=np.uint8)
+        dev = torch.device("cuda", 0)
+        dv = torch.from_numpy(views[:n].reshape(-1).copy() if n else np.zeros(16, dtype=np.uint8)).to(dev)
+        dl = torch.from_numpy(np.frombuffer(bytes(longs) + b"\0" * 16, dtype=np.uint8).copy()).to(dev)
+        total = sum(len(r) for r in rows)
+        torch.cuda.synchronize()
+        if n == 0:
+            dv = dv[:0]
+        off, val = ctx.column_from_views(dv, dl, total)
+        ctx.synchronize()
+        eo = np.zeros(n + 1, dtype=np.uint32)
+        eo[1:] = np.cumsum([len(r) for r in rows], dtype=np.uint64).astype(np.uint32)
+        assert (off.cpu().numpy().view(np.uint32) == eo).all(), n
+        assert bytes(val.cpu().numpy()[:total]) == b"".join(rows), n

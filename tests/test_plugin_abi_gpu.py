@@ -244,3 +244,36 @@ def test_large_call_over_two_pipelines_lands_in_one_pinned_column(H, monkeypatch
         assert two.equals(one), m
     monkeypatch.setenv("POLARS_STRSIM_DEVICES", "0")
     H.call_plugin("levenshtein", a[:1000], b[:1000])  # (this thread's context goes back to one device)
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("measure", ["levenshtein", "jaro_winkler", "sorensen_dice"])
+def test_view_native_slices(H, monkeypatch, measure, parallel):
+    """view columns shipped as the views themselves (POLARS_STRSIM_VIEWS=1; the default of the engine-parallel mode)
+    and resolved on the device -- inline strings, strings beyond 12 bytes, long ones, non-ASCII, nulls in both columns, chunks at
+    odd boundaries, sliced arrays; several slices per call (the estimate of one slice sizes the next), both engine modes."""
+    import random
+    monkeypatch.setenv("POLARS_STRSIM_VIEWS", "1")
+    monkeypatch.setenv("POLARS_STRSIM_DIRECT_ROWS", "0")
+    monkeypatch.setenv("POLARS_STRSIM_SINGLE_SLICE_ROWS", "1000")
+    monkeypatch.setenv("POLARS_STRSIM_RAMP_ROWS", "16384")
+    monkeypatch.setenv("POLARS_STRSIM_SLICE_ROWS", "32768")
+    rng = random.Random(19)
+    A, B = gen.pairs(41, 60_000, gen.ASCII_LOWER, 0, 11)      # every string in its view
+    A2, B2 = gen.pairs(42, 30_000, gen.ASCII_LOWER, 0, 40)    # in and out of the views
+    A3, B3 = gen.pairs(43, 3_000, gen.MIXED, 0, 60)
+    A4, B4 = gen.pairs(44, 300, gen.ASCII_LOWER, 100, 1500)
+    A, B = A + A2 + A3 + A4, B + B2 + B3 + B4
+    order = list(range(len(A)))
+    rng.shuffle(order)
+    A, B = [A[i] for i in order], [B[i] for i in order]
+    A = [None if rng.random() < 0.05 else x for x in A]
+    B = [None if rng.random() < 0.05 else x for x in B]
+    pa_a, pa_b = pa.array(A, type=pa.string()), pa.array(B, type=pa.string())
+    ca = pa.chunked_array([pa_a[:7], pa_a[7:20_001], pa_a[20_001:20_001], pa_a[20_001:]])
+    cb = pa.chunked_array([pa_b[:50_000], pa_b[50_000:]])
+    exp = expect(measure, A, B)
+    check(H.call_plugin(measure, ca, cb, layout="vu", parallel=parallel), exp)
+    check(H.call_plugin(measure, pa_a[1234:80_000], pa_b[1234:80_000], layout="vu", parallel=parallel), exp[1234:80_000])
+    # one view column, one offsets column: the call packs as before
+    check(H.call_plugin(measure, ca, cb, layout=("vu", "u"), parallel=parallel), exp)

@@ -106,6 +106,28 @@ def test_output_validity_is_the_and_of_the_inputs(threads):
 
 
 @pytest.mark.parametrize("threads", [1, 4, 8])
+def test_view_native_packer(threads):
+    """pack_slice_views: the views leave as they lie, a null slot as the empty string, a string beyond 12 bytes in the
+    thread's segment of the long-string area with its offset in the view -- sized exactly, from an estimate that holds, and from
+    one that does not (the packer then sizes exactly itself); chunks at odd offsets, sliced arrays."""
+    rng = random.Random(13)
+    A, _ = gen.pairs(56, 70_000, gen.ASCII_LOWER + gen.MIXED, 0, 40)
+    A += ["x" * 13, "y" * 12, "", "z" * 300, "w" * 5000]
+    A = [None if rng.random() < 0.05 else x for x in A]
+    arr = pa.array(A, type=pa.string())
+    x = pa.chunked_array([arr[:20_001], arr[20_001:20_001], arr[20_001:]])
+    want = [(s or "").encode() for s in A]
+    for r0, r1 in ((0, len(A)), (1234, 66_000), (500, 500)):
+        for est in (None, 64, 0.01):
+            got, total = H.pack_views(x, r0, r1, threads=threads, long_bytes_per_row=est)
+            assert got == want[r0:r1], (r0, r1, est)
+            assert total == sum(len(b) for b in want[r0:r1])
+    sl = arr[777:50_777]  # non-zero Arrow offset
+    got, _ = H.pack_views(sl, 0, 50_000, threads=threads)
+    assert got == want[777:50_777]
+
+
+@pytest.mark.parametrize("threads", [1, 4, 8])
 def test_one_pass_packer(threads):
     """pack_slice_onepass: per-thread segments sized from a bytes-per-row budget, one length byte per row, no size pass -- equal
     to the plain-Python packing when the budget holds, a clean "no" when a segment overflows or a string exceeds 255 bytes."""
