@@ -28,6 +28,8 @@ int _strsim_test_pack_onepass(SeriesExport *series, uint64_t r0, uint64_t r1, ui
                               uint64_t val_cap, uint8_t *len_out, uint64_t *bytes_out, int *nseg_out);
 int _strsim_test_validity(SeriesExport *two_series, uint64_t *words, int64_t *null_count, double *vals, uint64_t *rows_out,
                           unsigned threads);
+int _strsim_test_pack_views(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t lbpr256, unsigned threads, uint8_t *views_out,
+                            uint8_t *long_out, uint64_t long_cap, uint64_t *span_out, uint64_t *bytes_out);
 }
 
 namespace {
@@ -236,6 +238,31 @@ void one_round(unsigned seed)
             CHECK(fits, "the one-pass packer took a slice with a string beyond 255 bytes");
             CHECK(bytes == want.size() && (want.empty() || memcmp(val.data(), want.data(), want.size()) == 0), "one-pass bytes differ");
             CHECK(want_len.empty() || memcmp(len.data(), want_len.data(), want_len.size()) == 0, "one-pass lengths differ");
+        }
+        CHECK(ex.se.release == nullptr, "the series was not released");
+    }
+    // ---- (2b) the view-native packer: the views as they lie + the strings beyond 12 bytes in per-thread segments
+    if (layout == L_VIEW) {
+        Exported ex(layout, rows, valid, rng);
+        const uint64_t r0 = rng() % n, r1 = r0 + rng() % (n - r0 + 1);
+        uint64_t want_bytes = 0;
+        for (uint64_t r = r0; r < r1; ++r) want_bytes += valid[r] ? rows[r].size() : 0;
+        std::vector<uint8_t> views((r1 - r0 + 8) * 16, 0xEE), lng(want_bytes + (r1 - r0) * 2 + (1u << 20), 0xEE);
+        uint64_t span = 0, bytes = 0;
+        const uint64_t est = (seed & 64) ? ~0ull : (uint64_t)(rng() % 3) * 256 * 8; // exact / an estimate that may not hold
+        const int rc = _strsim_test_pack_views(&ex.se, r0, r1, est, threads, views.data(), lng.data(), lng.size(), &span, &bytes);
+        CHECK(rc == 0, "pack_views rc %d (%s)", rc, _polars_plugin_get_last_error_message());
+        CHECK(bytes == want_bytes, "view-native packed size %llu / %llu", (unsigned long long)bytes, (unsigned long long)want_bytes);
+        for (uint64_t r = r0; r < r1; ++r) {
+            const std::string want = valid[r] ? rows[r] : std::string();
+            View w;
+            memcpy(&w, views.data() + (r - r0) * 16, 16);
+            CHECK(w.len == want.size(), "view length of row %llu", (unsigned long long)r);
+            uint32_t at;
+            memcpy(&at, w.rest + 8, 4);
+            const uint8_t *src = w.len <= 12 ? w.rest : lng.data() + at;
+            CHECK(w.len <= 12 || (uint64_t)at + w.len <= span, "long string of row %llu outside the shipped span", (unsigned long long)r);
+            CHECK(want.empty() || memcmp(src, want.data(), want.size()) == 0, "view-native bytes of row %llu", (unsigned long long)r);
         }
         CHECK(ex.se.release == nullptr, "the series was not released");
     }
