@@ -10,7 +10,7 @@ BASELINE.json names ("100 M rows @ 1/2/4/8 GPU") -- and each step's f64 shard is
 side stream, overlapped with the next step's kernels.  --scaling weak holds the config's row count per GPU instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- dominant kernel (k_lane_pairs) vs the HBM roof, from hipEvents on its own stream
+  roofline      -- dominant kernel (k_lane_stage) vs the HBM roof, from hipEvents on its own stream
   cpu_baseline  -- the CPU oracle (C restatement of the reference, "port") on a bounded sample
 """
 import argparse
@@ -138,6 +138,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if a.same_device:
+        # every rank on cuda:0 is a smoke test of the control flow, never a scaling measurement: RCCL refuses two ranks on one
+        # device, so it only exists with the gloo backend -- and the JSON line says so (config.distributed.same_device)
+        if a.backend == "nccl":
+            raise SystemExit("--same-device needs --backend gloo (RCCL wants one GPU per rank)")
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -147,6 +151,25 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
+
+    # who is really taking part: the world torch.distributed has formed, its backend, every rank's device (a scaling record must
+    # be readable without trusting the command line)
+    distributed = {"world_size": 1, "backend": None, "same_device": bool(a.same_device), "devices": None}
+    if world > 1:
+        assert dist.get_world_size() == world == a.gpus, (dist.get_world_size(), world, a.gpus)
+        cdev0 = dev if a.backend == "nccl" else "cpu"
+        props = torch.cuda.get_device_properties(dev)
+        ident = torch.tensor([rank, local_rank, torch.cuda.current_device(), int(getattr(props, "pci_bus_id", -1)),
+                              int(getattr(props, "pci_device_id", -1)), props.multi_processor_count], dtype=torch.int64, device=cdev0)
+        idents = [torch.zeros_like(ident) for _ in range(world)]
+        dist.all_gather(idents, ident)
+        devices = [{"rank": int(v[0]), "local_rank": int(v[1]), "cuda_device": int(v[2]), "pci_bus": int(v[3]), "pci_device": int(v[4]),
+                    "compute_units": int(v[5])} for v in idents]
+        distinct = len({(d["cuda_device"], d["pci_bus"], d["pci_device"]) for d in devices})
+        if not a.same_device and distinct != world:
+            raise SystemExit(f"{world} ranks but {distinct} distinct GPUs: {devices}")
+        distributed = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "same_device": bool(a.same_device),
+                       "distinct_devices": distinct, "devices": devices}
 
     cfg = W.CONFIGS[a.config]
     measure = a.measure or cfg[0]
@@ -344,7 +367,7 @@ def main():
                 traffic = tj[key]["traffic_bytes_per_launch"] * nparts  # per pass over the whole shard, like `achieved`
         except Exception:
             pass
-        # the dominant kernel: k_lane_pairs, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
+        # the dominant kernel: k_lane_stage, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
         # k_wave_pairs, timed together by the second event pair) takes longer -- cfg3 and cfg5
         dom_ms, dom_name = lane_ms, ("k_lane_stage<%s>" if len(measures) == 1 else "k_lane_stage_all (five outputs)%s") % (measures[0] if len(measures) == 1 else "")
         if wave_ms > 0.2 * lane_ms:
@@ -364,7 +387,8 @@ def main():
             "dtype": "u8/u32 bit-parallel, f64 epilogue", "data": "synthetic",
             "config": {"workload": f"{a.config}: {measure}, {total_rows} rows ({a.scaling} scaling: {rows} on rank 0), lengths "
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
-                       "rows_total": total_rows, "rows_rank0": rows, "preheat_steps": preheat_steps, "gather_f64_to_rank0": bool(gather),
+                       "rows_total": total_rows, "rows_rank0": rows, "preheat_steps": preheat_steps, "distributed": distributed,
+                       "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
                        "gather_verified": gather_ok, "gather_note": gather_note,

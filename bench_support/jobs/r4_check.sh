@@ -12,3 +12,4 @@ for l in open("gpurun_out/r4_check/bench_lines.jsonl"):
     d = json.loads(l); r = d["roofline"]
     print("%-70s %9.1f M/s  %8.4f ms/step  kernel %.4f + %.4f ms  frac %.4f  ops/step %s" % (d["metric"][:70], d["value"], d["ms_per_step"], r["kernel_ms"], r["wave_kernel_ms"], r["frac"], d["config"]["enqueued_kernels_and_copies_per_step"]))
 PY
+POLARS_STRSIM_VIEWS=0 python bench_support/bench_views.py 10000000 2>/dev/null | grep "views=0" | tee $OUT/engine_parallel.txt

@@ -42,6 +42,18 @@ def test_two_ranks_ship_and_verify(extra, transport):
     assert d["config"]["gather_transport"] == transport
     assert d["config"]["gather_verified"] is True
     assert d["config"]["codec_exceptions"] == 0
+    # the line audits itself: the world torch.distributed formed, its backend, every rank's device
+    dd = d["config"]["distributed"]
+    assert dd["world_size"] == 2 and dd["backend"] == "gloo" and dd["same_device"] is True
+    assert [x["rank"] for x in dd["devices"]] == [0, 1] and all(x["cuda_device"] == 0 for x in dd["devices"])
+
+
+def test_same_device_is_refused_with_rccl():
+    """Two ranks on one GPU are a smoke test of the control flow, not a measurement: only with the gloo backend."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--same-device", "--backend", "nccl", "--rows", "1000",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--same-device needs --backend gloo" in (r.stderr + r.stdout)
 
 
 @pytest.mark.parametrize("extra", [[], ["--no-codec"]])
