@@ -657,15 +657,22 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         }
         if (next_row0 < row_end) dma_offsets(next_row0);
         STAGE_STAMP(6);
-        // ---- F: rounds(j): wave w runs rounds w, 2W-1-w, 2W+w, ... of the length order (short + long = balanced)
+        // ---- F: rounds(j), 64 rows of the length order each
         __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have copies to issue or results to store
         {
+            // the t-th round from the LONG end goes to wave t, 2W-1-t, 2W+t, ... (long + short = balanced also when the block
+            // holds fewer than B rows of this kernel: cfg3 5.1 rounds per block, 2.70 -> 2.45 ms), and the rounds are cut from
+            // the long end too: the one that is not full holds the block's shortest texts, not its longest
+            const uint32_t nrounds = (nmine + 63u) >> 6;
 #pragma unroll 1
             for (int k = 0; k < STAGE_RPW; ++k) {
-                const uint32_t r = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
-                if (r * 64u >= nmine) continue;
+                const uint32_t t = (uint32_t)(k >> 1) * (2u * STAGE_WAVES) + ((k & 1) ? (uint32_t)(2 * STAGE_WAVES - 1) - wv : wv);
+                if (t >= nrounds) continue;
+                const uint32_t hi = nmine - 64u * t;                // positions of the length order below this round's end
+                const uint32_t first = hi >= 64u ? hi - 64u : 0u;   // its first position
+                const uint32_t in_round = hi - first;               // (>= 1)
                 __builtin_amdgcn_s_setprio(1); // descriptor + window fetch ahead of the waves that grind columns
-                const uint2 d = *desc_at(r * 64u + lane);
+                const uint2 d = *desc_at(first + lane);
                 uint32_t wt[8], wp[8];
                 stage_window(s_bytes, d.x & 0xFFFFu, wt);
                 stage_window(s_bytes, d.x >> 16, wp);
@@ -674,8 +681,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     #endif
                 STAGE_STAMP(7);
                 __builtin_amdgcn_s_setprio(0);
-                const uint32_t in_round = nmine - r * 64u; // (>= 1)
-                stage_compute<MEASURE, LUT>(lut, wt, wp, d.y, (in_round < 64u ? in_round : 64u) - 1u, s_code, s_word, s_val);
+                stage_compute<MEASURE, LUT>(lut, wt, wp, lane < in_round ? d.y : STAGE_DEAD, in_round - 1u, s_code, s_word, s_val);
                 STAGE_STAMP(8);
             }
         }
