@@ -130,31 +130,52 @@ __device__ __forceinline__ uint32_t wave_max_u8(uint32_t v)
     return m;
 }
 
+// The text of a round into the lanes' LDS columns: WT x 32 bytes from each lane's a0 on (WT: by the round's longest text, not
+// by its masks -- a Jaro row with a 100-byte a and a 10-byte b walks 100 columns of ONE-word masks, and a 10-byte text under a
+// 100-byte pattern fetches 32 bytes, not 128).  o / n: OR / AND of the dwords (lanes without a row: 0), a0w: the first dword.
+template <int WT>
+__device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint32_t totalA, bool has, uint32_t a0, uint32_t *txt_col,
+                                          uint32_t &o, uint32_t &n, uint32_t &a0w)
+{
+    uint32_t ta[8 * WT];
+#pragma unroll
+    for (int d = 0; d < 8 * WT; ++d) ta[d] = 0u;
+    if (has) load_window_any<8 * WT>(valA, (int64_t)a0, totalA, ta);
+    o = ta[0]; n = ta[0];
+#pragma unroll
+    for (int d = 1; d < 8 * WT; ++d) { o |= ta[d]; n &= ta[d]; }
+#pragma unroll
+    for (int d = 0; d < 8 * WT; ++d) txt_col[d * 64] = ta[d];
+    a0w = ta[0];
+}
+
+// W: words of the masks (by the round's longest PATTERN), wtw: 32-byte units of text to fetch (uniform, 1..4)
 template <int MEASURE, int W>
 __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
-                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t *txt_col, bool &done, double &res)
+                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, uint32_t *txt_col, bool &done, double &res)
 {
-    uint32_t ta[8 * W], wp[8 * W];
+    uint32_t wp[8 * W];
 #pragma unroll
-    for (int d = 0; d < 8 * W; ++d) { ta[d] = 0u; wp[d] = 0u; }
-    uint32_t b0w = 0u;
+    for (int d = 0; d < 8 * W; ++d) wp[d] = 0u;
+    uint32_t b0w = 0u, a0w = 0u;
     bool fast = has;
     uint32_t vary = 0u;
+    if (has) load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
+    uint32_t o, n;
+    if (wtw <= 1u) wide_text<1>(valA, totalA, has, a0, txt_col, o, n, a0w);
+    else if (wtw == 2u) wide_text<2>(valA, totalA, has, a0, txt_col, o, n, a0w);
+    else if (wtw == 3u) wide_text<3>(valA, totalA, has, a0, txt_col, o, n, a0w);
+    else wide_text<4>(valA, totalA, has, a0, txt_col, o, n, a0w);
     if (has) {
-        load_window_any<8 * W>(valA, (int64_t)a0, totalA, ta);
-        load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
         if (MEASURE == JARO_WINKLER) b0w = wp[0];
-        uint32_t o = ta[0] | wp[0], n = ta[0] & wp[0];
 #pragma unroll
-        for (int d = 1; d < 8 * W; ++d) { o |= ta[d] | wp[d]; n &= ta[d] & wp[d]; }
+        for (int d = 0; d < 8 * W; ++d) { o |= wp[d]; n &= wp[d]; }
         uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
         uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
         vary = (o8 ^ n8) & 0xFFu;
         fast = (o8 & 0x80u) == 0u; // any high bit in the windows: leave the row to the code-point kernel
     }
-#pragma unroll
-    for (int d = 0; d < 8 * W; ++d) txt_col[d * 64] = ta[d];
     const uint32_t lae = fast ? la : 1u, lbe = fast ? lb : 1u;
     const uint32_t ng4 = (wave_max_u8(fast ? la : 0u) + 3u) >> 2;
     const uint32_t gfull = (255u - wave_max_u8(255u - (fast ? la : 255u))) >> 2; // text dwords before the shortest live text ends
@@ -168,8 +189,8 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const uint32_t nb4 = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? (wave_max_u8(fast ? lb : 0u) + 3u) >> 2 : 0u;
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation)
     __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue
-    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
-    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, nb4, ta[0], b0w, sa);
+    if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, nb4, a0w, b0w, sa);
+    else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, nb4, a0w, b0w, sa);
     __builtin_amdgcn_s_setprio(1);
     done = fast;
 }
@@ -195,9 +216,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     // 64 rows at a time.  The longer the list, the more alike the rows of a round: cfg3's rounds ran 74 % of their
     // lane-columns on a row that needed them with lists of one span (4 096 rows, 24 keys of 8 / 16 columns), 90 % with the whole
     // super and keys of 4 columns.  A super whose candidates do not fit the list (WIDE_LIST entries) is done span by span.
-    // 3 width classes (masks of 2 / 3 / 4 words) x 32 column counts (4 columns each) x 4 quarters of the pattern length (Jaro's
-    // second pass walks the pattern as far as the round's longest one reaches)
-    constexpr int NKEY = 384, KPL = NKEY / 64;
+    // 4 width classes (masks of 1 .. 4 words: by the pattern; one word = a Jaro row whose a is the long side) x 32 column
+    // counts (4 columns each) x 4 quarters of the class's pattern lengths (Jaro's second pass walks the pattern as far as the
+    // round's longest one reaches)
+    constexpr int NKEY = 512, KPL = NKEY / 64;
     __shared__ unsigned long long s_mask[WIDE_BLOCK];
     __shared__ uint32_t s_cnt[NKEY];            // rows per key, then the key's next free list position
     __shared__ uint32_t s_next, s_total;        // next round to hand out; rows on the list
@@ -240,8 +262,8 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
             const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
             if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0xFFFFu;
             const uint32_t steps = SYMMETRIC ? mn : la8, pat = SYMMETRIC ? mx : lb8;
-            const uint32_t cls = mx > 96u ? 2u : (mx > 64u ? 1u : 0u); // masks of 4 / 3 / 2 words
-            return (cls * 32u + ((steps - 1u) >> 2)) * 4u + (pat - 1u) / (8u * (cls + 2u));
+            const uint32_t cls = (pat - 1u) >> 5; // masks of cls + 1 words: as wide as the PATTERN is long
+            return (cls * 32u + ((steps - 1u) >> 2)) * 4u + (pat - 1u - 32u * cls) / 8u;
         };
 #pragma unroll 1
         for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
@@ -294,40 +316,62 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
             //      (a four-word round costs four times a two-word one: dealing them out in turn leaves waves idle at the
             //      barrier behind the list)
             const uint32_t nrounds = (total + 63u) >> 6;
-            for (;;) {
+            // a round's rows and their offsets are fetched one round AHEAD: list entry -> offsets -> windows are three dependent
+            // trips (LDS, then two scattered global loads), and three waves per SIMD do not hide two of the latter per round
+            struct Rows { bool valid, has; uint32_t i, a0, la, b0, lb; };
+            auto take = [&]() -> Rows {
+                Rows q{false, false, 0u, 0u, 0u, 0u, 0u};
                 uint32_t rr = 0u;
                 if (lane == 0u) rr = atomicAdd(&s_next, 1u);
                 rr = uniform(rr);
-                if (rr >= nrounds) break;
-                const uint32_t r = nrounds - 1u - rr;
-                const uint32_t li = r * 64u + lane;
-                const bool has = li < total;
-                const uint32_t i = has ? s_list[li] : 0u;
-                const uint64_t row = cw0 * 64u + i;
-                uint32_t a0 = 0, la = 0, b0 = 0, lb = 0;
-                if (has) {
+                if (rr >= nrounds) return q;
+                q.valid = true;
+                // (cut from the long end: the round that is not full holds the list's cheapest rows, not its dearest)
+                const uint32_t hi = total - 64u * rr, first = hi >= 64u ? hi - 64u : 0u;
+                const uint32_t li = first + lane;
+                q.has = li < hi;
+                q.i = q.has ? s_list[li] : 0u;
+                if (q.has) {
+                    const uint64_t row = cw0 * 64u + q.i;
                     const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-                    a0 = offA[ra]; la = offA[ra + 1] - a0;
-                    b0 = offB[rb]; lb = offB[rb + 1] - b0;
+                    q.a0 = offA[ra]; q.la = offA[ra + 1] - q.a0;
+                    q.b0 = offB[rb]; q.lb = offB[rb + 1] - q.b0;
                 }
+                return q;
+            };
+            Rows cur = take();
+            while (cur.valid) {
+                const Rows nxt = take();
+                const bool has = cur.has;
+                const uint32_t i = cur.i, a0 = cur.a0, la = cur.la, b0 = cur.b0, lb = cur.lb;
+                const uint64_t row = cw0 * 64u + i;
                 const bool swap = SYMMETRIC && la > lb; // symmetric measures walk the shorter string
                 const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
                 const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
                 const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
-                const bool wide3 = __ballot(has && (la > 64u || lb > 64u)) != 0ull;
-                const bool wide4 = __ballot(has && (la > 96u || lb > 96u)) != 0ull;
+                const bool pat2 = __ballot(has && lp > 32u) != 0ull, pat3 = __ballot(has && lp > 64u) != 0ull;
+                const bool pat4 = __ballot(has && lp > 96u) != 0ull;
+                const uint32_t wtw = 1u + (__ballot(has && lt > 32u) != 0ull) + (__ballot(has && lt > 64u) != 0ull) +
+                                     (__ballot(has && lt > 96u) != 0ull);
                 bool done = false;
                 double res = 0.0;
-                if (!wide3)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
-                else if (!wide4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
+                bool one_word = false;
+                if constexpr (!SYMMETRIC) { // (the symmetric measures' pattern is the longer string: two words or more)
+                    one_word = !pat2;
+                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                }
+                if (one_word) {
+                } else if (!pat3)
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                else if (!pat4)
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
                 else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, &s_txt[wv][0][lane], done, res);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
                 if (done) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
+                cur = nxt;
             }
         }
         lds_barrier();
@@ -444,9 +488,10 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
             __syncthreads();
             const uint32_t nrounds = (total + 63u) >> 6;
             for (uint32_t rr = wv; rr < nrounds; rr += WIDE_WAVES) {
-                const uint32_t r = nrounds - 1u - rr;
-                const uint32_t li = r * 64u + lane;
-                const bool has = li < total;
+                // (cut from the long end: the round that is not full holds the list's cheapest rows, not its dearest)
+                const uint32_t hi = total - 64u * rr, first = hi >= 64u ? hi - 64u : 0u;
+                const uint32_t li = first + lane;
+                const bool has = li < hi;
                 const uint32_t i = has ? s_list[li] : 0u;
                 const uint64_t row = c0 * 64u + i;
                 uint32_t a0 = 0, la8 = 0, b0 = 0, lb8 = 0;

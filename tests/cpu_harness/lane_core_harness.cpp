@@ -224,6 +224,54 @@ extern "C" double harness_lane_pair_wide(int measure, int W, const uint8_t *a, u
     return run_wide_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
 }
 
+// Masks as wide as the PATTERN (lb <= 32 * W), the text of any length up to 128 bytes: k_lane_wide's Jaro / Jaro-Winkler rounds
+// whose a is the long side (and what the cores allow for every measure)
+template <int M, int W>
+static double run_wide_tp(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
+{
+    uint32_t ta[32], wp[8 * W];
+    uint8_t buf[32 * W];
+    std::memset(ta, fill, sizeof ta);
+    std::memcpy(ta, a, la);
+    std::memset(buf, fill, sizeof buf);
+    std::memcpy(buf, b, lb);
+    std::memcpy(wp, buf, sizeof buf);
+    const uint32_t b0w = wp[0];
+    uint32_t o = 0, n = 0xFFFFFFFFu;
+    for (int d = 0; d < 32; ++d) { o |= ta[d]; n &= ta[d]; }
+    for (int d = 0; d < 8 * W; ++d) { o |= wp[d]; n &= wp[d]; }
+    uint32_t o8 = o | (o >> 16); o8 |= o8 >> 8;
+    uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
+    const int np = force_np ? force_np : planes_needed((o8 ^ n8) & 0xFFu);
+    switch (np) {
+    case 5: return run_wide_np<M, 5, W>(ta, la, wp, lb, b0w);
+    case 6: return run_wide_np<M, 6, W>(ta, la, wp, lb, b0w);
+    default: return run_wide_np<M, 7, W>(ta, la, wp, lb, b0w);
+    }
+}
+
+template <int W>
+static double run_wide_tp_m(int measure, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb, int force_np, uint8_t fill)
+{
+    switch (measure) {
+    case LEVENSHTEIN: return run_wide_tp<LEVENSHTEIN, W>(a, la, b, lb, force_np, fill);
+    case JARO: return run_wide_tp<JARO, W>(a, la, b, lb, force_np, fill);
+    case JARO_WINKLER: return run_wide_tp<JARO_WINKLER, W>(a, la, b, lb, force_np, fill);
+    case JACCARD: return run_wide_tp<JACCARD, W>(a, la, b, lb, force_np, fill);
+    default: return run_wide_tp<SORENSEN_DICE, W>(a, la, b, lb, force_np, fill);
+    }
+}
+
+// a: 1..128 bytes (the text), b: 1..32*W bytes (the pattern)
+extern "C" double harness_lane_pair_wide_tp(int measure, int W, const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb,
+                                            int force_np, int fill)
+{
+    if (W == 1) return run_wide_tp_m<1>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 2) return run_wide_tp_m<2>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    if (W == 3) return run_wide_tp_m<3>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+    return run_wide_tp_m<4>(measure, a, la, b, lb, force_np, (uint8_t)fill);
+}
+
 // ---- symbol (non-ASCII) cores ----------------------------------------------------------------------
 struct SymArr { const uint16_t *s; uint32_t operator()(uint32_t k) const { return s[k]; } };
 struct EmitArr { uint16_t *s; void operator()(uint32_t k, uint32_t cp) const { if (k < 40) s[k] = (uint16_t)cp; } };

@@ -33,6 +33,8 @@ def harness():
     L.harness_lane_pair.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_wide.restype = C.c_double
     L.harness_lane_pair_wide.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
+    L.harness_lane_pair_wide_tp.restype = C.c_double
+    L.harness_lane_pair_wide_tp.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_sym.restype = C.c_double
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
     L.harness_lev_snap.restype = C.c_uint32
@@ -138,6 +140,28 @@ def test_wide_cores_random_bit_exact(harness, measure, W):
             for force, fill in ((0, alphabet[n % len(alphabet)]), (7, 0)):
                 got = harness.harness_lane_pair_wide(O.MEASURE_ID[measure], W, a, len(a), b, len(b), force, fill)
                 assert bits(got) == bits(exp), (measure, W, a, b, got, exp)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+@pytest.mark.parametrize("W", [1, 2, 3, 4])
+def test_wide_cores_masks_as_wide_as_the_pattern(harness, measure, W):
+    """k_lane_wide sizes its masks by the pattern alone: a Jaro row with a 100-byte a and a 10-byte b runs one-word masks
+    over 100 columns (strsim.rs:200-237 walks a against b whatever their lengths)."""
+    rng = random.Random(2000 + W)
+    lens_a = (1, 5, 31, 32, 33, 40, 63, 64, 65, 96, 97, 127, 128)
+    lens_b = sorted({1, 2, 7, 32 * W - 1, 32 * W, max(1, 32 * W - 16), max(1, 32 * (W - 1) + 1)})
+    for alphabet in (b"ab", b"abcdefghijklmnopqrstuvwxyz", bytes(range(1, 128))):
+        for la in lens_a:
+            for lb in lens_b:
+                for _ in range(4):
+                    a = bytes(rng.choice(alphabet) for _ in range(la))
+                    b = bytes(rng.choice(alphabet) for _ in range(lb))
+                    if rng.random() < 0.5:  # related strings: matches, transpositions, shared characters
+                        b = bytes(rng.choice(a) for _ in range(lb))
+                    exp = O.pair(measure, a, b)
+                    for force, fill in ((0, alphabet[(la + lb) % len(alphabet)]), (7, 0)):
+                        got = harness.harness_lane_pair_wide_tp(O.MEASURE_ID[measure], W, a, la, b, lb, force, fill)
+                        assert bits(got) == bits(exp), (measure, W, a, b, got, exp)
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
