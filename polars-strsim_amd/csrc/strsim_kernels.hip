@@ -100,14 +100,39 @@ __device__ __forceinline__ void load_window_any(const uint8_t *__restrict__ vals
     }
 }
 
+// A lane's text in LDS: 128 bytes of its own ("row" = LDS byte address, a multiple of 128), byte k at row + (k ^ swz) with
+// swz = (lane & 31) << 2 -- dword g of all 64 lanes lies in 32 different banks (two lanes per bank: the LDS's natural rate), and
+// the address of a byte or a dword is ONE v_xad_u32 ((k ^ swz) + row).  [r4] Columns of dwords, [dword][lane], had the same
+// banks and a three-instruction byte address; Jaro's string of matched characters is written once per column of a and read
+// once per position of b (33..128-byte frame: Jaro / Jaro-Winkler +4 %).
+__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t xad_s(uint32_t a, uint32_t b, uint32_t c) // (a: wave-uniform, from a scalar register)
+{
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    return r;
+}
 struct LdsTxt {
-    const uint32_t *col; // &s_txt[wave][0][lane], dword g at col[g * 64]
-    __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return col[g * 64u]; }
+    uint32_t row, swz;
+    __device__ __forceinline__ uint32_t at(uint32_t g) const { return xad_s(g << 2, swz, row); } // (g: uniform)
+    __device__ __forceinline__ uint32_t operator()(uint32_t g) const
+    {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)at(g));
+    }
+    __device__ __forceinline__ void put(uint32_t g, uint32_t v) const
+    {
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)at(g)) = v;
+    }
 };
-// Jaro's string of matched characters (strsim_lane_wide.h): byte k of the lane's text column -- dword k / 4 at col[(k / 4) * 64]
+// Jaro's string of matched characters (strsim_lane_wide.h) overwrites the front of the lane's text
 struct LdsSa {
-    uint32_t base; // LDS byte address of the lane's column (a multiple of 4)
-    __device__ __forceinline__ uint32_t at(uint32_t k) const { return ((k >> 2) << 8) + ((k & 3u) | base); } // three instructions
+    uint32_t row, swz;
+    __device__ __forceinline__ uint32_t at(uint32_t k) const { return xad(k, swz, row); }
     // Unconditional: a character that found no partner is overwritten by the next one that does (k does not move), and what
     // is left behind the last match is never read.
     __device__ __forceinline__ void put(uint32_t k, uint32_t c, uint32_t) const
@@ -134,7 +159,7 @@ __device__ __forceinline__ uint32_t wave_max_u8(uint32_t v)
 // by its masks -- a Jaro row with a 100-byte a and a 10-byte b walks 100 columns of ONE-word masks, and a 10-byte text under a
 // 100-byte pattern fetches 32 bytes, not 128).  o / n: OR / AND of the dwords (lanes without a row: 0), a0w: the first dword.
 template <int WT>
-__device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint32_t totalA, bool has, uint32_t a0, uint32_t *txt_col,
+__device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint32_t totalA, bool has, uint32_t a0, const LdsTxt &txt,
                                           uint32_t &o, uint32_t &n, uint32_t &a0w)
 {
     uint32_t ta[8 * WT];
@@ -145,7 +170,7 @@ __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint
 #pragma unroll
     for (int d = 1; d < 8 * WT; ++d) { o |= ta[d]; n &= ta[d]; }
 #pragma unroll
-    for (int d = 0; d < 8 * WT; ++d) txt_col[d * 64] = ta[d];
+    for (int d = 0; d < 8 * WT; ++d) txt.put((uint32_t)d, ta[d]);
     a0w = ta[0];
 }
 
@@ -153,7 +178,7 @@ __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint
 template <int MEASURE, int W>
 __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
-                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, uint32_t *txt_col, bool &done, double &res)
+                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res)
 {
     uint32_t wp[8 * W];
 #pragma unroll
@@ -163,10 +188,10 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     uint32_t vary = 0u;
     if (has) load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
     uint32_t o, n;
-    if (wtw <= 1u) wide_text<1>(valA, totalA, has, a0, txt_col, o, n, a0w);
-    else if (wtw == 2u) wide_text<2>(valA, totalA, has, a0, txt_col, o, n, a0w);
-    else if (wtw == 3u) wide_text<3>(valA, totalA, has, a0, txt_col, o, n, a0w);
-    else wide_text<4>(valA, totalA, has, a0, txt_col, o, n, a0w);
+    if (wtw <= 1u) wide_text<1>(valA, totalA, has, a0, txt, o, n, a0w);
+    else if (wtw == 2u) wide_text<2>(valA, totalA, has, a0, txt, o, n, a0w);
+    else if (wtw == 3u) wide_text<3>(valA, totalA, has, a0, txt, o, n, a0w);
+    else wide_text<4>(valA, totalA, has, a0, txt, o, n, a0w);
     if (has) {
         if (MEASURE == JARO_WINKLER) b0w = wp[0];
 #pragma unroll
@@ -183,8 +208,7 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     if (__ballot(fast) == 0ull) return;
     const bool need7 = __ballot(fast && (vary & 0x40u)) != 0ull;
     const bool need6 = __ballot(fast && (vary & 0x20u)) != 0ull;
-    const LdsTxt txt{txt_col};
-    const LdsSa sa{STRSIM_LDS_ADDR(txt_col)};
+    const LdsSa sa{txt.row, txt.swz};
     // Jaro's second pass walks b: as far as the round's longest one reaches
     const uint32_t nb4 = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? (wave_max_u8(fast ? lb : 0u) + 3u) >> 2 : 0u;
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation)
@@ -355,18 +379,19 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                                      (__ballot(has && lt > 96u) != 0ull);
                 bool done = false;
                 double res = 0.0;
+                const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
                 bool one_word = false;
                 if constexpr (!SYMMETRIC) { // (the symmetric measures' pattern is the longer string: two words or more)
                     one_word = !pat2;
-                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
                 }
                 if (one_word) {
                 } else if (!pat3)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
                 else if (!pat4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
                 else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, &s_txt[wv][0][lane], done, res);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
                 if (done) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));

@@ -300,7 +300,7 @@ STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_
 // per column of a against about ten per position of b here, and the flags of a (kept in LDS between the passes) are gone.
 // ---------------------------------------------------------------------------------------------
 template <int NP, int W, class Txt, class Sa>
-STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, uint32_t nb4, const uint32_t (&P)[NP][W],
+STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, uint32_t lb, uint32_t nb4, const uint32_t (&P)[NP][W],
                          const uint32_t (&wp)[8 * W], const Sa &sa, uint32_t &m_out, uint32_t &t_out)
 {
     // Instruction diet: the two window masks move along as carry chains (himask is not clamped to lb -- the
@@ -315,29 +315,39 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
 #pragma unroll
     for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
     uint32_t m = 0u;
-    uint32_t left = la - 1u; // la - 1 - i: negative from column la on
-    for (uint32_t g = 0; g < ng4; ++g) {
+    // a column: TAIL = some lane's text may have ended (dead: all ones once i >= la); the text dwords below gfull run without it
+    auto column = [&](uint32_t c4, int ii, uint32_t i, uint32_t dead, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        uint32_t Eq[W], cand[W], d[W];
+        eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
+            cand[w] = TAIL ? bitop3<0x10>(inwin, fb[w], dead) : (inwin & ~fb[w]); // inwin & ~fb (& ~dead)
+        }
+        minus1_wide(cand, d);
+#pragma unroll
+        for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
+        const uint32_t hit = any_wide<W>(cand);
+        sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
+        m = add_nz(m, hit);
+        shl1_one(himask);
+        shl1_ge(lomask, i, bound);
+    };
+    uint32_t g = 0;
+    for (; g < gfull && g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) column(c4, ii, 4u * g + (uint32_t)ii, 0u, std::false_type{});
+    }
+    uint32_t left = la - 1u - 4u * g; // la - 1 - i: negative from column la on
+    for (; g < ng4; ++g) {
         const uint32_t c4 = txt(g);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-            const uint32_t i = 4u * g + (uint32_t)ii;
-            const uint32_t dead = sign_fill(left); // all ones once i >= la
+            const uint32_t dead = sign_fill(left);
             left -= 1u;
-            uint32_t Eq[W], cand[W], d[W];
-            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
-                cand[w] = bitop3<0x10>(inwin, fb[w], dead);                       // inwin & ~fb & ~dead
-            }
-            minus1_wide(cand, d);
-#pragma unroll
-            for (int w = 0; w < W; ++w) fb[w] = bitop3<0xF4>(fb[w], cand[w], d[w]); // fb | (cand & ~(cand - 1))
-            const uint32_t hit = any_wide<W>(cand);
-            sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
-            m = add_nz(m, hit);
-            shl1_one(himask);
-            shl1_ge(lomask, i, bound);
+            column(c4, ii, 4u * g + (uint32_t)ii, dead, std::true_type{});
         }
     }
     uint32_t t = 0u, k = 0u;
@@ -364,26 +374,36 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb,
 
 // Multiset intersection size, W words (see multiset_isect32).
 template <int NP, int W, class Txt>
-STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W])
+STRSIM_HD uint32_t isect_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, uint32_t lb, const uint32_t (&P)[NP][W])
 {
     uint32_t lbmask[W], used[W];
     low_ones_wide<W>(lb, lbmask);
 #pragma unroll
     for (int w = 0; w < W; ++w) used[w] = 0u;
-    uint32_t left = la - 1u; // la - 1 - i: negative from column la on
-    for (uint32_t g = 0; g < ng4; ++g) {
+    auto column = [&](uint32_t c4, int ii, uint32_t dead, auto tail) { // (TAIL: as in jaro_wide)
+        constexpr bool TAIL = decltype(tail)::value;
+        uint32_t Eq[W], cand[W], d[W];
+        eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
+#pragma unroll
+        for (int w = 0; w < W; ++w) cand[w] = TAIL ? bitop3<0x10>(Eq[w], used[w], dead) : (Eq[w] & ~used[w]); // Eq & ~used (& ~dead)
+        minus1_wide(cand, d);
+#pragma unroll
+        for (int w = 0; w < W; ++w) used[w] = bitop3<0xF4>(used[w], cand[w], d[w]); // used | lowest candidate
+    };
+    uint32_t g = 0;
+    for (; g < gfull && g < ng4; ++g) {
+        const uint32_t c4 = txt(g);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) column(c4, ii, 0u, std::false_type{});
+    }
+    uint32_t left = la - 1u - 4u * g; // la - 1 - i: negative from column la on
+    for (; g < ng4; ++g) {
         const uint32_t c4 = txt(g);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const uint32_t dead = sign_fill(left);
             left -= 1u;
-            uint32_t Eq[W], cand[W], d[W];
-            eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
-#pragma unroll
-            for (int w = 0; w < W; ++w) cand[w] = bitop3<0x10>(Eq[w], used[w], dead); // Eq & ~used & ~dead
-            minus1_wide(cand, d);
-#pragma unroll
-            for (int w = 0; w < W; ++w) used[w] = bitop3<0xF4>(used[w], cand[w], d[w]); // used | lowest candidate
+            column(c4, ii, dead, std::true_type{});
         }
     }
     uint32_t n = 0u;
@@ -408,11 +428,11 @@ STRSIM_HD double lane_wide_result(const Txt &txt, uint32_t la, uint32_t gfull, u
         return epilogue_levenshtein(lev_wide<NP, W>(txt, la, gfull, ng4, P, lb), la, lb);
     } else if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         uint32_t m, t;
-        jaro_wide<NP, W>(txt, la, ng4, lb, nb4, P, wp, sa, m, t);
+        jaro_wide<NP, W>(txt, la, gfull, ng4, lb, nb4, P, wp, sa, m, t);
         const double j = epilogue_jaro(m, t, la, lb);
         return MEASURE == JARO ? j : epilogue_jaro_winkler(j, common_prefix4(a0w, la, b0w, lb));
     } else {
-        const uint32_t isect = isect_wide<NP, W>(txt, la, ng4, lb, P);
+        const uint32_t isect = isect_wide<NP, W>(txt, la, gfull, ng4, lb, P);
         return MEASURE == JACCARD ? epilogue_jaccard(isect, la, lb) : epilogue_sorensen_dice(isect, la, lb);
     }
 }
