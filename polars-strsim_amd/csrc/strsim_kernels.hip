@@ -2061,18 +2061,16 @@ static void launch_lane_t(const LaunchArgs &a)
         // bytes staged through LDS (strsim_lane_stage.h): persistent workgroups, one per resident slot
         const uint64_t nsb = (a.n + (STAGE_ROWS - 1)) / STAGE_ROWS;
         // (a.stage_grid counts STRSIM_STAGE_WAVES_PER_EU workgroups per CU; an instantiation that runs fewer gets its share)
-        auto go = [&](auto tables) {
-            constexpr bool T = decltype(tables)::value;
-            const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M, T>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
+        auto go = [&](auto tables, auto long_rows) {
+            constexpr bool T = decltype(tables)::value, L = decltype(long_rows)::value;
+            const uint64_t res = (uint64_t)a.stage_grid * (uint64_t)stage_waves_per_eu<M, T, L>() / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
             const uint64_t gs = stage_launch_size(nsb, res, (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU);
-            hipLaunchKernelGGL((k_lane_stage<M, T>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
+            hipLaunchKernelGGL((k_lane_stage<M, T, L>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                                a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
         };
-        if constexpr (stage_uses_lut<M>()) {
-            if (a.long_rows) go(std::false_type{}); else go(std::true_type{});
-        } else {
-            go(std::false_type{});
-        }
+        if (a.long_rows) go(std::false_type{}, std::true_type{});
+        else if constexpr (stage_uses_lut<M>()) go(std::true_type{}, std::false_type{});
+        else go(std::false_type{}, std::false_type{});
     }
     if (a.ev_lane1) (void)hipEventRecord(a.ev_lane1, a.stream);
 }

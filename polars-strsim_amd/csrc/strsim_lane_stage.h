@@ -32,6 +32,9 @@
 #ifndef STRSIM_STAGE_CAP
 #define STRSIM_STAGE_CAP 10240 // staged bytes per column and block (cfg2: 512 rows are 8.4 KB +- 0.2 KB; a block that does not fit is cut)
 #endif
+#ifndef STRSIM_STAGE_CAP_LONG
+#define STRSIM_STAGE_CAP_LONG 15104 // the same for the long-row geometry (40 KB of LDS: four workgroups per CU; cfg3: 13 312 2.02 ms, 14 336 1.95, 15 104 1.88)
+#endif
 #ifndef STRSIM_STAGE_CAP_LUT
 #define STRSIM_STAGE_CAP_LUT 8960 // the same for the instantiations with match-mask tables (40 KB of LDS: four workgroups per CU)
 #endif
@@ -82,8 +85,13 @@ constexpr int STAGE_RPW = STAGE_NR / STAGE_WAVES;     // rounds per wave and blo
 template <int MEASURE> constexpr bool stage_uses_lut() { return ((STRSIM_STAGE_LUT >> MEASURE) & 1) != 0; } // (5: five outputs)
 
 // staged bytes per column: Levenshtein keeps 16 bits per row for the store phase, the other measures 32 (64: five outputs)
-template <bool TABLES> struct StageGeom {
-    static constexpr int CAP = TABLES ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP;
+// LONG: the geometry for frames of long strings (the launcher takes it when the context's last call left more than 1/16 of its
+// rows to the later kernels): cfg3's rows average 26 bytes per column, 10 KB cut its blocks at 345 rows of which 185 are this
+// kernel's -- 3.4 rounds for four waves and the per-block chain (copy, sort, store) for 2/3 of a block.  15 KB hold 512 rows
+// (275 of this kernel's: 4.3 rounds) at four workgroups per CU: cfg3 2.24 -> 1.88 ms.
+template <bool TABLES, bool LONG = false> struct StageGeom {
+    static_assert(!(TABLES && LONG), "the long-row geometry has no match-mask tables");
+    static constexpr int CAP = LONG ? STRSIM_STAGE_CAP_LONG : (TABLES ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP);
     static constexpr int COL = CAP + 96;              // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
     static constexpr int DMA_ITERS = (CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
     static_assert(CAP % 16 == 0 && 2 * COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
@@ -309,7 +317,7 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
     }
 }
 
-template <int MEASURE, bool LUT>
+template <int MEASURE, bool LUT, bool LONG = false>
 __device__ __forceinline__ void
 lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs,
@@ -320,8 +328,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
     constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
-    constexpr int STAGE_CAP = StageGeom<LUT>::CAP, STAGE_COL = StageGeom<LUT>::COL;
-    constexpr int STAGE_DMA_ITERS = StageGeom<LUT>::DMA_ITERS;
+    constexpr int STAGE_CAP = StageGeom<LUT, LONG>::CAP, STAGE_COL = StageGeom<LUT, LONG>::COL;
+    constexpr int STAGE_DMA_ITERS = StageGeom<LUT, LONG>::DMA_ITERS;
     constexpr uint32_t COLB = STAGE_COL, LIT = 2u * STAGE_COL; // s_bytes: column a | column b | the literals' windows
     // Match-mask tables (strsim_lane_lut.h), for the measures that use them: per wave 3 KB at a 4 KB boundary -- entry e of
     // lane l at e * 256 + l * 4, and the boundary makes (table base >> 8) | e the address byte.
@@ -736,23 +744,22 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
 #define STRSIM_STAGE_ALL_WAVES_PER_EU 3
 #endif
-template <int MEASURE, bool TABLES> constexpr int stage_waves_per_eu()
+template <int MEASURE, bool TABLES, bool LONG = false> constexpr int stage_waves_per_eu()
 {
-    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : (TABLES ? 4 : 5);
+    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : ((TABLES || LONG) ? 4 : 5);
     return STRSIM_STAGE_WAVES_PER_EU < lim ? STRSIM_STAGE_WAVES_PER_EU : lim;
 }
 
-// TABLES: match masks from the LDS tables (a measure whose bit is set in STRSIM_STAGE_LUT has both instantiations; the launcher
-// takes the one without tables for frames with many rows this kernel leaves to the others -- long strings: what the kernel does
-// there is mostly staging, which the larger staging area and the fifth workgroup per CU serve better; cfg3: 2.86 vs 2.57 ms)
-template <int MEASURE, bool TABLES>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE, TABLES>()))) void
+// TABLES: match masks from the LDS tables (a measure whose bit is set in STRSIM_STAGE_LUT); LONG: the long-row geometry
+// (StageGeom), without tables -- what the kernel does on such frames is mostly staging.
+template <int MEASURE, bool TABLES, bool LONG = false>
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_waves_per_eu(stage_waves_per_eu<MEASURE, TABLES, LONG>()))) void
 k_lane_stage(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, uint64_t rowsA,
              const uint32_t *__restrict__ offB, const uint8_t *__restrict__ valB, uint64_t rowsB, OutPtrs outs, uint64_t n,
              unsigned long long *__restrict__ slowmask, DevStatus *__restrict__ status, const double *__restrict__ qtab,
              uint32_t *__restrict__ sched, DevStatus *__restrict__ publish, uint32_t ticket)
 {
-    lane_stage_body<MEASURE, TABLES>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
+    lane_stage_body<MEASURE, TABLES, LONG>(offA, valA, rowsA, offB, valB, rowsB, outs, n, slowmask, status, qtab, sched, publish, ticket);
 }
 
 // The five-output instantiation keeps the matching state of three cores alive at once and stages 64 bits per row.
