@@ -155,6 +155,22 @@ __device__ __forceinline__ uint32_t wave_max_u8(uint32_t v)
     return m;
 }
 
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+// lab build only (make EXTRA="-DSTRSIM_LAB -DSTRSIM_WIDE_STAMPS"): per-wave cycle sums of the phases of k_lane_wide, read back with
+// strsim_debug_wide_stamps() (bench_support/wide_stamps.py).  [0] mask + collect (keys, scan, list) [1] a round's rows and
+// offsets [2] windows -> registers / LDS, the tests [3] the cores [4] result + mask bit [5] the barrier behind the list
+// [6] rounds [10] all [11] all (100 MHz)
+__device__ unsigned long long g_wide_stamps[16384][16];
+#define WIDE_STAMP(cat) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                             __builtin_amdgcn_sched_barrier(0); wst_acc[cat] += t_ - wst_last; wst_last = t_; } while (0)
+#define WIDE_STAMP_PARAMS , unsigned long long (&wst_acc)[8], unsigned long long &wst_last
+#define WIDE_STAMP_ARGS , wst_acc, wst_last
+#else
+#define WIDE_STAMP(cat) do { } while (0)
+#define WIDE_STAMP_PARAMS
+#define WIDE_STAMP_ARGS
+#endif
+
 // The text of a round into the lanes' LDS columns: WT x 32 bytes from each lane's a0 on (WT: by the round's longest text, not
 // by its masks -- a Jaro row with a 100-byte a and a 10-byte b walks 100 columns of ONE-word masks, and a 10-byte text under a
 // 100-byte pattern fetches 32 bytes, not 128).  o / n: OR / AND of the dwords (lanes without a row: 0), a0w: the first dword.
@@ -178,7 +194,7 @@ __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint
 template <int MEASURE, int W>
 __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
-                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res)
+                                           uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res WIDE_STAMP_PARAMS)
 {
     uint32_t wp[8 * W];
 #pragma unroll
@@ -213,6 +229,7 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const uint32_t nb4 = (MEASURE == JARO || MEASURE == JARO_WINKLER) ? (wave_max_u8(fast ? lb : 0u) + 3u) >> 2 : 0u;
     // two instantiations per width (a six-plane one only inflated the kernel's register allocation)
     __builtin_amdgcn_s_setprio(0); // the column loops yield to waves that have loads to issue
+    WIDE_STAMP(2);
     if (need7 || need6) res = lane_wide_result<MEASURE, 7, W>(txt, lae, gfull, ng4, wp, lbe, nb4, a0w, b0w, sa);
     else res = lane_wide_result<MEASURE, 5, W>(txt, lae, gfull, ng4, wp, lbe, nb4, a0w, b0w, sa);
     __builtin_amdgcn_s_setprio(1);
@@ -254,6 +271,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     constexpr int RPS = WIDE_ROWS / WIDE_BLOCK; // rows per thread and span in the collection phase
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     __builtin_amdgcn_s_setprio(1);
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+    unsigned long long wst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long wst_t0 = __builtin_amdgcn_s_memtime(), wst_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wst_last = wst_t0;
+#endif
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1;
     const uint64_t nchunks = (n + 63u) >> 6;
@@ -278,11 +300,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         //      the rounds start (64 keys per thread in registers cost more than the kernel has: 1.6 KB of scratch per lane).
         uint16_t *const s_key = reinterpret_cast<uint16_t *>(&s_txt[0][0][0]);
         static_assert(sizeof(s_txt) >= (size_t)WIDE_BLOCK * 64 * 2, "a 16-bit key per row of a super");
-        auto row_key = [&](uint32_t i) -> uint32_t { // 0xFFFF: not a candidate
+        // The lengths of ALL rows of a span are loaded first, RPS rows per thread in flight at once (consecutive threads, consecutive
+        // rows: whole lines), and only then looked at: loads behind the test of the row's mask bit wait for their data one row
+        // at a time -- 64 round trips per thread and super, 23 % of the kernel's time on cfg3 ([r4], bench_support/wide_stamps.py).
+        auto row_key = [&](uint32_t i, uint32_t la8, uint32_t lb8) -> uint32_t { // 0xFFFF: not a candidate
             if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0xFFFFu;
-            const uint64_t row = cw0 * 64u + i;
-            const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-            const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
             const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
             if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0xFFFFu;
             const uint32_t steps = SYMMETRIC ? mn : la8, pat = SYMMETRIC ? mx : lb8;
@@ -291,10 +313,19 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         };
 #pragma unroll 1
         for (uint32_t sp = g0; sp < g0 + gsz; ++sp) {
+            uint32_t la8[RPS], lb8[RPS];
 #pragma unroll
             for (int kk = 0; kk < RPS; ++kk) {
                 const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
-                const uint32_t key = row_key(i);
+                const uint64_t r = cw0 * 64u + i, row = r < n ? r : n - 1u; // (rows behind the frame: their mask bits are clear)
+                const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                la8[kk] = offA[ra + 1] - offA[ra];
+                lb8[kk] = offB[rb + 1] - offB[rb];
+            }
+#pragma unroll
+            for (int kk = 0; kk < RPS; ++kk) {
+                const uint32_t i = (sp * RPS + (uint32_t)kk) * WIDE_BLOCK + tid;
+                const uint32_t key = row_key(i, la8[kk], lb8[kk]);
                 s_key[i] = (uint16_t)key;
                 if (key != 0xFFFFu) atomicAdd(&s_cnt[key], 1u);
             }
@@ -363,9 +394,15 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 }
                 return q;
             };
+            WIDE_STAMP(0);
             Rows cur = take();
             while (cur.valid) {
                 const Rows nxt = take();
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                wst_acc[6] += 1;
+#endif
+                WIDE_STAMP(1);
                 const bool has = cur.has;
                 const uint32_t i = cur.i, a0 = cur.a0, la = cur.la, b0 = cur.b0, lb = cur.lb;
                 const uint64_t row = cw0 * 64u + i;
@@ -383,28 +420,39 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 bool one_word = false;
                 if constexpr (!SYMMETRIC) { // (the symmetric measures' pattern is the longer string: two words or more)
                     one_word = !pat2;
-                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
+                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
                 }
                 if (one_word) {
                 } else if (!pat3)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
                 else if (!pat4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
                 else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
+                WIDE_STAMP(3);
                 if (done) {
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
                 cur = nxt;
+                WIDE_STAMP(4);
             }
         }
         lds_barrier();
+        WIDE_STAMP(5);
         g0 += gsz;
       }
       if (tid < super_words && cw0 + tid < nchunks) slowmask[cw0 + tid] = s_mask[tid];
       lds_barrier();
     }
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+    if (lane == 0u) {
+        const uint32_t w = (blockIdx.x * WIDE_WAVES + wv) & 16383u;
+        for (int q = 0; q < 8; ++q) g_wide_stamps[w][q] = wst_acc[q];
+        g_wide_stamps[w][10] = __builtin_amdgcn_s_memtime() - wst_t0;
+        g_wide_stamps[w][11] = __builtin_amdgcn_s_memrealtime() - wst_r0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2280,6 +2328,16 @@ hipError_t launch_publish_status(const DevStatus *src, DevStatus *dst_mapped, ui
 
 } // namespace strsim
 
+
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+// lab build only: copies the per-wave phase cycle sums of the last k_lane_wide launch to the host
+extern "C" __attribute__((visibility("default"))) int strsim_debug_wide_stamps(unsigned long long *dst, size_t waves)
+{
+    if (waves > 16384) waves = 16384;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(strsim::g_wide_stamps), waves * 16 * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 
 #if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
 // lab build only: copies the per-wave phase cycle sums of the last k_lane_stage launch to the host
