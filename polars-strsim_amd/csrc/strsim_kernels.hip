@@ -171,9 +171,98 @@ __device__ unsigned long long g_wide_stamps[16384][16];
 #define WIDE_STAMP_ARGS
 #endif
 
-// The text of a round into the lanes' LDS columns: WT x 32 bytes from each lane's a0 on (WT: by the round's longest text, not
-// by its masks -- a Jaro row with a 100-byte a and a 10-byte b walks 100 columns of ONE-word masks, and a 10-byte text under a
-// 100-byte pattern fetches 32 bytes, not 128).  o / n: OR / AND of the dwords (lanes without a row: 0), a0w: the first dword.
+// ---- a round's windows, fetched by the wave TOGETHER ------------------------------------------------------------------
+// [r4] Each lane used to fetch its own row's windows: 16-byte loads from 64 unrelated places per instruction (the address unit
+// works through them one cache line at a time; the 8 pieces of a 128-byte window came in 8 instructions, so lines were fetched
+// from L2 again and again: 2.9-5.8 x the rows' bytes), and a wave sat 28 % of its time behind them.  Now LPR
+// consecutive lanes fetch consecutive 16-byte pieces of ONE row (LPR = 2, 4 or 8 pieces per row; 64 / LPR rows per instruction,
+// LPR instructions per 64 rows), the pieces go through the wave's LDS rows (128 bytes per lane, the text's home anyway), and
+// every lane picks up its own row there.
+typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
+template <int NCH> struct CoopGeom {
+    static constexpr int LPR = NCH <= 2 ? 2 : (NCH <= 4 ? 4 : 8); // lanes per row
+    static constexpr int RPI = 64 / LPR;                           // rows per instruction
+    static constexpr int ITER = LPR;                               // instructions per 64 rows
+};
+// piece c (0 .. NCH-1; lanes with c >= NCH idle) of row it * RPI + lane / LPR, it = 0 .. ITER-1; `start`: the owner lane's byte
+// offset of its window.  The caller has checked that all NCH pieces of every row lie inside the column (a round that touches
+// the column's last bytes takes the lane-by-lane path, wide_text / load_window_any).
+// (`vals` is the OWNER's column -- the symmetric measures take their text from either -- so its address travels with `start`)
+template <int NCH>
+__device__ __forceinline__ void coop_fetch(const uint8_t *vals, uint32_t start, uint32_t lane, uint4 (&v)[CoopGeom<NCH>::ITER])
+{
+    using G = CoopGeom<NCH>;
+    const uint32_t c = lane & (uint32_t)(G::LPR - 1), rsub = lane / (uint32_t)G::LPR;
+    const uint64_t mine = (uint64_t)reinterpret_cast<uintptr_t>(vals) + start;
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const uint32_t r = (uint32_t)(it * G::RPI) + rsub;
+        const uint64_t p = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)r) << 32) | (uint32_t)__shfl((int)(uint32_t)mine, (int)r);
+        const u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(reinterpret_cast<const uint8_t *>((uintptr_t)p) + 16u * (c < (uint32_t)NCH ? c : 0u));
+        v[it] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+}
+// the pieces -> the wave's LDS rows, 16-byte groups swizzled by the row (group c of row r at r * 128 + ((c ^ r) & 7) * 16), dwords in
+// order: the PATTERN's layout -- its owner reads it back into registers with wide_pattern_regs
+template <int NCH>
+__device__ __forceinline__ void coop_store_groups(uint32_t base, uint32_t lane, const uint4 (&v)[CoopGeom<NCH>::ITER])
+{
+    using G = CoopGeom<NCH>;
+    const uint32_t c = lane & (uint32_t)(G::LPR - 1), rsub = lane / (uint32_t)G::LPR;
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const uint32_t r = (uint32_t)(it * G::RPI) + rsub;
+        if (c < (uint32_t)NCH)
+        {
+            u32x4_lds q;
+            q.x = v[it].x; q.y = v[it].y; q.z = v[it].z; q.w = v[it].w;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4_lds *>((uintptr_t)(base + r * 128u + (((c ^ r) & 7u) << 4))) = q;
+        }
+    }
+}
+template <int W>
+__device__ __forceinline__ void wide_pattern_regs(uint32_t base, uint32_t lane, uint32_t (&wp)[8 * W])
+{
+#pragma unroll
+    for (int c = 0; c < 2 * W; ++c) {
+        const u32x4_lds q = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_lds *>((uintptr_t)(base + lane * 128u + ((((uint32_t)c ^ lane) & 7u) << 4)));
+        wp[4 * c] = q.x; wp[4 * c + 1] = q.y; wp[4 * c + 2] = q.z; wp[4 * c + 3] = q.w;
+    }
+}
+// the pieces -> the TEXT's layout (LdsTxt: dword g of row r at r * 128 + ((g ^ r) & 31) * 4)
+template <int NCH>
+__device__ __forceinline__ void coop_store_text(uint32_t base, uint32_t lane, const uint4 (&v)[CoopGeom<NCH>::ITER])
+{
+    using G = CoopGeom<NCH>;
+    const uint32_t c = lane & (uint32_t)(G::LPR - 1), rsub = lane / (uint32_t)G::LPR;
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const uint32_t r = (uint32_t)(it * G::RPI) + rsub;
+        if (c < (uint32_t)NCH) {
+            const uint32_t row = base + r * 128u, swz = (r & 31u) << 2;
+            const uint32_t e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(row + ((16u * c + 4u * (uint32_t)k) ^ swz))) = e[k];
+        }
+    }
+}
+// a lane's own text row: OR / AND of its first 32 * WT bytes (whole 16-byte groups: the swizzle only permutes inside them)
+template <int WT>
+__device__ __forceinline__ void wide_text_or_and(const LdsTxt &txt, uint32_t &o, uint32_t &n)
+{
+    o = 0u; n = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < 2 * WT; ++c) {
+        const u32x4_lds q = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_lds *>((uintptr_t)(txt.row + (((uint32_t)c << 4) ^ (txt.swz & 0x70u))));
+        o |= q.x | q.y | q.z | q.w;
+        n &= q.x & q.y & q.z & q.w;
+    }
+}
+
+// The lane-by-lane path (a round with a window that reaches past its column's last byte; rounds of the first launches before
+// ... no: any round): WT x 32 bytes from each lane's a0 on into its LDS row.  o / n: OR / AND of the dwords (lanes without a
+// row: 0), a0w: the first dword.
 template <int WT>
 __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint32_t totalA, bool has, uint32_t a0, const LdsTxt &txt,
                                           uint32_t &o, uint32_t &n, uint32_t &a0w)
@@ -197,17 +286,46 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
                                            uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res WIDE_STAMP_PARAMS)
 {
     uint32_t wp[8 * W];
-#pragma unroll
-    for (int d = 0; d < 8 * W; ++d) wp[d] = 0u;
     uint32_t b0w = 0u, a0w = 0u;
     bool fast = has;
     uint32_t vary = 0u;
-    if (has) load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
-    uint32_t o, n;
-    if (wtw <= 1u) wide_text<1>(valA, totalA, has, a0, txt, o, n, a0w);
-    else if (wtw == 2u) wide_text<2>(valA, totalA, has, a0, txt, o, n, a0w);
-    else if (wtw == 3u) wide_text<3>(valA, totalA, has, a0, txt, o, n, a0w);
-    else wide_text<4>(valA, totalA, has, a0, txt, o, n, a0w);
+    // (opaque: the LDS addresses below depend on the lane alone, and hoisted out of the kernel's loops -- eight instructions' worth
+    //  for each of the twelve piece geometries -- they are a hundred registers that live in scratch)
+    uint32_t lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    const uint32_t base = txt.row - lane * 128u; // the wave's 64 rows of 128 bytes
+    uint32_t o = 0u, n = 0u;
+    // (windows: 32 W bytes of pattern, 32 wtw bytes of text; a lane without a row fetches its column's first bytes)
+    const bool edge = __ballot(has && ((uint64_t)b0 + 32u * (uint32_t)W > totalB || (uint64_t)a0 + 32u * wtw > totalA)) != 0ull ||
+                      totalB < 32u * (uint32_t)W || totalA < 32u * wtw;
+    if (!edge) {
+        // both fetches in flight together; the pattern passes through the rows first, then the text moves in
+        const uint32_t pstart = has ? b0 : 0u, tstart = has ? a0 : 0u;
+        uint4 vp[CoopGeom<2 * W>::ITER];
+        coop_fetch<2 * W>(valB, pstart, lane, vp);
+        auto text = [&](auto wt) {
+            constexpr int WT = decltype(wt)::value;
+            uint4 vt[CoopGeom<2 * WT>::ITER];
+            coop_fetch<2 * WT>(valA, tstart, lane, vt);
+            coop_store_groups<2 * W>(base, lane, vp);
+            wide_pattern_regs<W>(base, lane, wp);
+            coop_store_text<2 * WT>(base, lane, vt);
+            wide_text_or_and<WT>(txt, o, n);
+        };
+        if (wtw <= 1u) text(std::integral_constant<int, 1>{});
+        else if (wtw == 2u) text(std::integral_constant<int, 2>{});
+        else if (wtw == 3u) text(std::integral_constant<int, 3>{});
+        else text(std::integral_constant<int, 4>{});
+        a0w = txt(0u);
+    } else { // a window reaches past its column's last byte: lane by lane, byte by byte where it must
+#pragma unroll
+        for (int d = 0; d < 8 * W; ++d) wp[d] = 0u;
+        if (has) load_window_any<8 * W>(valB, (int64_t)b0, totalB, wp);
+        if (wtw <= 1u) wide_text<1>(valA, totalA, has, a0, txt, o, n, a0w);
+        else if (wtw == 2u) wide_text<2>(valA, totalA, has, a0, txt, o, n, a0w);
+        else if (wtw == 3u) wide_text<3>(valA, totalA, has, a0, txt, o, n, a0w);
+        else wide_text<4>(valA, totalA, has, a0, txt, o, n, a0w);
+    }
     if (has) {
         if (MEASURE == JARO_WINKLER) b0w = wp[0];
 #pragma unroll
