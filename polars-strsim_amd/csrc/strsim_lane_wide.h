@@ -105,6 +105,25 @@ STRSIM_HD void shl1_ge(uint32_t (&x)[4], uint32_t a, uint32_t b)
         "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
         : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "s"(a), "v"(b) : "vcc");
 }
+// x = (x << 1) | (a <= b)
+STRSIM_HD void shl1_le(uint32_t (&x)[1], uint32_t a, uint32_t b) { x[0] = x[0] + x[0] + (a <= b ? 1u : 0u); }
+STRSIM_HD void shl1_le(uint32_t (&x)[2], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_le_u32_e32 vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(x[0]), "+v"(x[1]) : "s"(a), "v"(b) : "vcc"); // (a: the column index + 1, wave-uniform)
+}
+STRSIM_HD void shl1_le(uint32_t (&x)[3], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_le_u32_e32 vcc, %3, %4\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "s"(a), "v"(b) : "vcc");
+}
+STRSIM_HD void shl1_le(uint32_t (&x)[4], uint32_t a, uint32_t b)
+{
+    asm("v_cmp_le_u32_e32 vcc, %4, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "s"(a), "v"(b) : "vcc");
+}
 // (x << 1) | (v != 0), one word
 STRSIM_HD uint32_t shl1_nz(uint32_t x, uint32_t v)
 {
@@ -138,6 +157,7 @@ STRSIM_HD void minus1_wide(const uint32_t (&x)[4], uint32_t (&d)[4])
 #else
 template <int W> STRSIM_HD void shl1_one(uint32_t (&x)[W]) { shl1_in<W>(x, 1u); }
 template <int W> STRSIM_HD void shl1_ge(uint32_t (&x)[W], uint32_t a, uint32_t b) { shl1_in<W>(x, a >= b ? 1u : 0u); }
+template <int W> STRSIM_HD void shl1_le(uint32_t (&x)[W], uint32_t a, uint32_t b) { shl1_in<W>(x, a <= b ? 1u : 0u); }
 STRSIM_HD uint32_t shl1_nz(uint32_t x, uint32_t v) { return (x << 1) | (v ? 1u : 0u); }
 STRSIM_HD uint32_t add_nz(uint32_t x, uint32_t v) { return x + (v ? 1u : 0u); }
 template <int W> STRSIM_HD void minus1_wide(const uint32_t (&x)[W], uint32_t (&d)[W])
@@ -303,17 +323,20 @@ template <int NP, int W, class Txt, class Sa>
 STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t ng4, uint32_t lb, uint32_t nb4, const uint32_t (&P)[NP][W],
                          const uint32_t (&wp)[8 * W], const Sa &sa, uint32_t &m_out, uint32_t &t_out)
 {
-    // Instruction diet: the two window masks move along as carry chains (himask is not clamped to lb -- the
-    // match masks already are), "this column is past the end of a" is the sign of a running counter, the lowest candidate is
-    // folded into the flags with one three-input op per word.
+    // Instruction diet: the window mask moves along as a carry chain, "this column is past the end of a" is the
+    // sign of a running counter (and only looked at from the text dword on in which some lane's text ends: gfull), the lowest
+    // candidate is folded into the flags with one three-input op per word.
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u;
-    uint32_t lbmask[W], himask[W], lomask[W], fb[W];
+    // the match window as ONE mask: ones at [i - bound, i + bound] (from 0 on while i < bound; not clamped to lb -- the match
+    // masks already are): (win << 1) | (i < bound) moves it along.  [r4] Two masks ([0, i + bound] and [0, i - bound)), two carry
+    // chains and two mask operations per word and column before.
+    uint32_t lbmask[W], win[W], fb[W];
     low_ones_wide<W>(lb, lbmask);
-    low_ones_wide<W>(bound + 1u, himask); // ones at [0, i + bound]
+    low_ones_wide<W>(bound + 1u, win);
 #pragma unroll
-    for (int w = 0; w < W; ++w) { lomask[w] = 0u; fb[w] = 0u; }
+    for (int w = 0; w < W; ++w) fb[w] = 0u;
     uint32_t m = 0u;
     // a column: TAIL = some lane's text may have ended (dead: all ones once i >= la); the text dwords below gfull run without it
     auto column = [&](uint32_t c4, int ii, uint32_t i, uint32_t dead, auto tail) {
@@ -322,8 +345,8 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t n
         eq_wide<NP, W>(P, lbmask, c4, ii, Eq);
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            const uint32_t inwin = bitop3<0x40>(Eq[w], himask[w], lomask[w]); // Eq & himask & ~lomask
-            cand[w] = TAIL ? bitop3<0x10>(inwin, fb[w], dead) : (inwin & ~fb[w]); // inwin & ~fb (& ~dead)
+            cand[w] = bitop3<0x40>(Eq[w], win[w], fb[w]); // Eq & win & ~fb
+            if (TAIL) cand[w] &= ~dead;
         }
         minus1_wide(cand, d);
 #pragma unroll
@@ -331,8 +354,7 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t n
         const uint32_t hit = any_wide<W>(cand);
         sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
         m = add_nz(m, hit);
-        shl1_one(himask);
-        shl1_ge(lomask, i, bound);
+        shl1_le(win, i + 1u, bound);
     };
     uint32_t g = 0;
     for (; g < gfull && g < ng4; ++g) {
