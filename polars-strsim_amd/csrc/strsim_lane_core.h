@@ -338,8 +338,9 @@ STRSIM_HD double epilogue_sorensen_dice(uint64_t isect, uint64_t la, uint64_t lb
 // multiset_isect32 above, all of it to spend fewer and cheaper instructions (bench_support/micro/op_cost.hip):
 //   * no `live` mask: in the column groups below tmin every lane's text is still running, from tmin on a column runs under
 //     `column < la` (the exec mask), so a lane whose text has ended simply stops updating ALL of its state;
-//   * the low edge of Jaro's window is a variable shift of all-ones by max(i - bound, 0) (a saturating subtract and one
-//     shift) instead of a mask that is shifted along under a compare;
+//   * Jaro's window is ONE mask, ones at [max(i - bound, 0), i + bound], moved along by an add with carry-in (i < bound); its
+//     upper end is not clamped to lb, the match masks are ([r4]; before: a mask for the upper edge, shifted and clamped, and a
+//     variable shift of all-ones for the lower one);
 //   * "a_i found a partner" is `cand != 0`, and the lowest candidate goes into the flags with one three-input op.
 // la, lb >= 1; tmin <= la <= tmax, both lane-uniform.  Outputs: dist (edit distance), m / t (Jaro matches, unequal zipped
 // pairs NOT halved), isect (sum of min counts); only those of the cores switched on are written.
@@ -355,15 +356,17 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
     const uint32_t mx = la > lb ? la : lb;
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u; // mx/2 - 1 (:200); mx == 1 only for the 1x1 case, window {i}
-    uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb); // ones at [0, min(i+bound, lb-1)]
+    uint32_t win = low_ones(bound + 1u); // Jaro's window, ones at [max(i - bound, 0), i + bound]: (win << 1) | (i < bound) moves it along
     uint32_t fb = 0u, fa = 0u;
+    // (the match masks end at lb when Jaro is on: its window does not; the recurrence of Levenshtein never looks down from there)
+    const uint32_t valid = DO_JARO ? lbmask : 0xFFFFFFFFu;
     // multiset intersection
     uint32_t used = 0u;
 #pragma unroll
     for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
         if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
         auto column = [&](int i) {
-            const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
+            const uint32_t Eq = eq_mask<NP>(P, valid, wa[i >> 2], i & 3);
             if (DO_LEV) {
                 const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
                 const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
@@ -374,12 +377,10 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
             }
             if (DO_JARO) {
                 // candidates: equal, inside [max(i - bound, 0), min(i + bound, lb - 1)], not flagged yet
-                const uint32_t below = (uint32_t)i > bound ? (uint32_t)i - bound : 0u;   // (a saturating subtract)
-                const uint32_t notlow = 0xFFFFFFFFu << (below & 31u);                     // below <= 31
-                const uint32_t cand = bitop3<0x80>(Eq, himask, notlow) & ~fb;
+                const uint32_t cand = bitop3<0x40>(Eq, win, fb);                          // Eq & win & ~fb
                 fb = bitop3<0xF8>(fb, cand, 0u - cand);                                   // fb | lowest candidate
                 fa |= cand ? (1u << i) : 0u;
-                himask = ((himask << 1) | 1u) & lbmask;
+                win = win + win + ((uint32_t)i < bound ? 1u : 0u);
             }
             if (DO_ISECT) {
                 const uint32_t cand = bitop3<0x08>(used, Eq, lbmask);                     // ~used & Eq & lbmask

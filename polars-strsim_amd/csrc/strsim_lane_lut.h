@@ -202,7 +202,7 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
     const uint32_t mx = la > lb ? la : lb;                               // Jaro, first pass
     const uint32_t half = mx >> 1;
     const uint32_t bound = (half ? half : 1u) - 1u;                      // mx/2 - 1 (:200); mx == 1 only for the 1x1 case, window {i}
-    uint32_t himask = low_ones((bound + 1u) < lb ? (bound + 1u) : lb);  // ones at [0, min(i+bound, lb-1)]
+    uint32_t win = low_ones(bound + 1u);                                 // ones at [max(i - bound, 0), i + bound] (lane_cores32)
     uint32_t fb = 0u, fa = 0u;
     uint32_t used = 0u;                                                  // multiset intersection
     constexpr int CPT = COLS_PER_TEST, NG = 32 / COLS_PER_TEST;
@@ -215,7 +215,9 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
             const int j = CPT * g + jj;
             if ((j & 3) == 0 && j != 0) ix = lut_index(t, wa[(j >> 2) & 7]);
             const uint32_t l = lut_read(t, ix.l, j & 3), m = lut_read(t, ix.m, j & 3);
-            E[g][jj] = NP > 5 ? bitop3<0x80>(l, m, lut_high_planes<NP>(P, wa[(j >> 2) & 7], j & 3)) : (l & m);
+            // (the masks end at lb when Jaro is on, as in lane_cores32: one more input of the same three-input AND)
+            if (NP > 5) E[g][jj] = bitop3<0x80>(l, m, lut_high_planes<NP>(P, wa[(j >> 2) & 7], j & 3)) & (DO_JARO ? lbmask : 0xFFFFFFFFu);
+            else E[g][jj] = DO_JARO ? bitop3<0x80>(l, m, lbmask) : (l & m);
         }
     };
     unrolled_until<0, LUT_AHEAD>([&](auto gc) { fetch(gc); return true; });
@@ -236,12 +238,10 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
             }
             if (DO_JARO) {
                 // candidates: equal, inside [max(i - bound, 0), min(i + bound, lb - 1)], not flagged yet
-                const uint32_t below = (uint32_t)i > bound ? (uint32_t)i - bound : 0u;   // (a saturating subtract)
-                const uint32_t notlow = 0xFFFFFFFFu << (below & 31u);                     // below <= 31
-                const uint32_t cand = bitop3<0x80>(Eq, himask, notlow) & ~fb;
+                const uint32_t cand = bitop3<0x40>(Eq, win, fb);                          // Eq & win & ~fb
                 fb = bitop3<0xF8>(fb, cand, 0u - cand);                                   // fb | lowest candidate
                 fa |= cand ? (1u << i) : 0u;
-                himask = ((himask << 1) | 1u) & lbmask;
+                win = win + win + ((uint32_t)i < bound ? 1u : 0u);
             }
             if (DO_ISECT) {
                 const uint32_t cand = bitop3<0x08>(used, Eq, lbmask);                     // ~used & Eq & lbmask
