@@ -20,6 +20,7 @@ for l in open("gpurun_out/r4_final/bench_lines.jsonl"):
 PY
 python bench_support/jobs/small_frames.py > $OUT/small_frames.txt 2>/dev/null
 python bench_support/bench_literal.py > $OUT/literal.txt 2>/dev/null
+python bench_support/bench_mid_ascii.py 2>/dev/null | tail -5 > $OUT/mid_ascii.txt
 bash bench_support/jobs/plugin_e2e.sh > $OUT/plugin_e2e.txt 2>&1
 for extra in "" "--no-codec"; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --same-device --backend gloo --rows 4000000 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e $extra 2>/dev/null | tail -1 >> $OUT/bench_2rank_gloo_one_gpu.jsonl
