@@ -13,15 +13,16 @@ import strsim_amd as S
 from bench_support import workload as W
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 dev = torch.device("cuda", 0)
-_, _, law, lo, hi, seed = W.CONFIGS["cfg2"]
+measure, _, law, lo, hi, seed = W.CONFIGS[cfg]
 oa, va, ob, vb, _, _ = W.device_columns(seed, law, lo, hi, 0, rows, dev)
 out = torch.empty(rows, dtype=torch.float64, device=dev)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ctx = S.Context(0, stream=st.cuda_stream)
 for _ in range(30):
-    ctx.pairs_device("levenshtein", oa, va, ob, vb, out=out)
+    ctx.pairs_device(measure, oa, va, ob, vb, out=out)
 ctx.synchronize()
 torch.cuda.synchronize()
 L = S.lib()

@@ -644,15 +644,21 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
         __syncthreads();
         const bool any = __ballot(s_mask[lane & (U8_SPAN - 1)] != 0ull) != 0ull; // same answer in every wave
         if (any) {
-            uint32_t key[RPT], rank[RPT];
+            uint32_t key[RPT], rank[RPT], len_a[RPT], len_b[RPT];
+            // (the lengths of all RPT rows in flight at once, whole lines; looked at afterwards -- as in k_lane_wide [r4])
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const uint64_t r = c0 * 64u + (uint32_t)k * WIDE_BLOCK + tid, row = r < n ? r : n - 1u;
+                const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
+                len_a[k] = offA[ra + 1] - offA[ra];
+                len_b[k] = offB[rb + 1] - offB[rb];
+            }
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const uint32_t i = k * WIDE_BLOCK + tid;
                 key[k] = 0xFFFFFFFFu;
                 if ((s_mask[i >> 6] >> (i & 63u)) & 1ull) {
-                    const uint64_t row = c0 * 64u + i;
-                    const uint64_t ra = bcastA ? 0 : row, rb = bcastB ? 0 : row;
-                    const uint32_t la8 = offA[ra + 1] - offA[ra], lb8 = offB[rb + 1] - offB[rb];
+                    const uint32_t la8 = len_a[k], lb8 = len_b[k];
                     const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
                     if (mx <= 128u && mx >= 1u) { // an empty side is fine here: the result is 0.0 without any DP
                         (void)mn;

@@ -232,6 +232,38 @@ def test_wide_rows_at_every_list_density(S, ctx, measure, density):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+def test_wide_rows_mask_and_text_width_classes(S, ctx, measure):
+    """k_lane_wide sizes its masks by the PATTERN (b for Jaro / Jaro-Winkler, the longer string for the symmetric measures) and
+    fetches the text by its own length: every (text class, pattern class) pair of 32-byte classes, in a frame large enough for
+    rounds whose windows the wave fetches together (the last rows of the columns take the lane-by-lane path), with copies and
+    transposed copies so that Jaro finds matches at every distance (strsim.rs:200-237)."""
+    import random
+    rng = random.Random(77)
+    edges = (1, 2, 16, 31, 32, 33, 48, 63, 64, 65, 80, 95, 96, 97, 112, 127, 128)
+    A, B = [], []
+    for rep in range(24):
+        for la in edges:
+            for lb in edges:
+                if max(la, lb) <= 32 and rep:  # (the 32-byte kernel's rows: once is enough here)
+                    continue
+                a = [rng.choice("abcdefghijklmnop") for _ in range(la)]
+                kind = rng.random()
+                if kind < 0.35:
+                    b = [rng.choice("abcdefghijklmnop") for _ in range(lb)]
+                elif kind < 0.7:  # an edited copy
+                    b = (a * (lb // max(la, 1) + 1))[:lb]
+                    for _ in range(rng.randint(0, 5)):
+                        b[rng.randrange(lb)] = rng.choice("abcxyz")
+                else:  # a copy with neighbours swapped: transpositions
+                    b = (a * (lb // max(la, 1) + 1))[:lb]
+                    for k in range(0, lb - 1, rng.choice((2, 3, 5))):
+                        b[k], b[k + 1] = b[k + 1], b[k]
+                A.append("".join(a)); B.append("".join(b))
+    got = gpu(S, ctx, measure, A, B)
+    assert_bit_exact(got, O.batch_strings(measure, A, B, 16), A, B, measure)
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_length_class_boundaries(S, ctx, measure):
     import random
     rng = random.Random(5)
