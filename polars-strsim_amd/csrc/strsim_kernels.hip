@@ -11,8 +11,9 @@
 //                     each lane picks its two 32-byte windows out of LDS, transposes one into bit-planes and runs the
 //                     bit-parallel cores of strsim_lane_core.h in registers.  k_lane_stage_all: five outputs from one pass.
 //   k_lane_lit<M>     a column against a Utf8 literal (strsim_lane_lit.h): the literal is the wave-uniform text.
-//   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with 2-, 3- or 4-word masks
-//                     (strsim_lane_wide.h), text in an LDS column per lane.
+//   k_lane_wide<M>    ONE PAIR PER LANE, 33..128 ASCII bytes: the same cores with masks of 1..4 words -- as wide as the PATTERN
+//                     (strsim_lane_wide.h); the rows of a 16 384-row super sorted by (mask words, columns to run), a round's
+//                     windows fetched by the wave together through its LDS rows, where the text stays.
 //   k_lane_utf8<M>    ONE PAIR PER LANE, short non-ASCII strings (<= 32 scalar values, BMP): per-lane UTF-8 decode
 //                     into 16-bit symbols in LDS, then the same cores on symbols (strsim_lane_sym.h).
 //   k_wave_pairs<M>   the rest, up to WAVE_CAP bytes, any UTF-8, taken chunk by chunk from a work list k_lane_utf8 builds.
@@ -50,11 +51,12 @@ struct OutPtrs {
 #include "strsim_lane_lit.h"
 
 // ------------------------------------------------------------------------------------------------
-// k_lane_wide: one pair per lane for the rows k_lane_stage left behind whose strings are 33..128 ASCII
-// bytes: W = 2 (<= 64), 3 (<= 96) or 4 (<= 128) word masks (strsim_lane_wide.h).  A workgroup takes a span of
-// WIDE_SPAN mask words (2048 rows), collects the flagged rows of each width class into LDS lists and runs
-// them 64 at a time; finished rows are cleared from the mask, the rest (non-ASCII, longer, empty side)
-// stay for k_wave_pairs.  With nothing flagged a span costs one 256-byte read.
+// k_lane_wide: one pair per lane for the rows k_lane_stage left behind whose longer string is 33..128 ASCII
+// bytes: masks of W = 1..4 words, as wide as the PATTERN (strsim_lane_wide.h: b for Jaro / Jaro-Winkler, the longer
+// string for the symmetric measures).  A workgroup takes a super of up to 256 mask words (16 384 rows), sorts its flagged
+// rows into an LDS list by (W, columns to run) and runs them 64 at a time; finished rows are cleared from the mask,
+// the rest (non-ASCII, longer, empty side) stay for k_lane_utf8 / k_wave_pairs.  With nothing flagged a super costs
+// one coalesced read and one barrier.
 // ------------------------------------------------------------------------------------------------
 constexpr int WIDE_BLOCK = 256;
 constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
@@ -260,9 +262,9 @@ __device__ __forceinline__ void wide_text_or_and(const LdsTxt &txt, uint32_t &o,
     }
 }
 
-// The lane-by-lane path (a round with a window that reaches past its column's last byte; rounds of the first launches before
-// ... no: any round): WT x 32 bytes from each lane's a0 on into its LDS row.  o / n: OR / AND of the dwords (lanes without a
-// row: 0), a0w: the first dword.
+// The lane-by-lane path (a round with a window that reaches past its column's last byte, a literal side): WT x 32 bytes from each
+// lane's a0 on into its LDS row, byte by byte where the column ends.  o / n: OR / AND of the dwords (lanes without a row: 0),
+// a0w: the first dword.
 template <int WT>
 __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint32_t totalA, bool has, uint32_t a0, const LdsTxt &txt,
                                           uint32_t &o, uint32_t &n, uint32_t &a0w)
@@ -354,10 +356,11 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     done = fast;
 }
 
-// Register budget: on its own the compiler takes 157 (Levenshtein, Jaccard, Dice) to 199 (Jaro) VGPRs = 3 / 2 waves per
-// SIMD; asked for 3 it fits 168 and spills ~40 registers in the four-word Jaro path, and cfg3 still gains 11 %
-// (7.50 -> 8.34 G pairs/s).  Two kernels, one per width, so that the two-word rows run at 4 waves per SIMD were tried:
-// 8.13 G on cfg3 and -10 % on a 33-128-byte frame (a second scan + collect pass, half-empty rounds).
+// Register budget: three waves per SIMD (168 VGPRs): Levenshtein / Jaccard / Dice take 162, Jaro / Jaro-Winkler 165-167, nothing
+// spilled ([r4]: one window mask instead of two, and the text no longer waits in 32 registers beside the pattern's 32; rounds
+// 1-3: ~40 spilled in the four-word Jaro path).  LDS (53.5 KB) allows three workgroups per CU as well.  Two kernels, one per
+// width, so that the two-word rows run at 4 waves per SIMD were tried in round 2: -2.5 % on cfg3 and -10 % on a
+// 33-128-byte frame (a second scan + collect pass, half-empty rounds).
 #ifndef STRSIM_WIDE_WAVES_PER_EU
 #define STRSIM_WIDE_WAVES_PER_EU 3
 #endif
