@@ -1,5 +1,7 @@
 #!/bin/bash
-# counters of one kernel for prebuilt library variants:
+# counters of one kernel for prebuilt library variants (ONE group of counters per call that the hardware can collect in one pass:
+# "FETCH_SIZE WRITE_SIZE TA_TA_BUSY_sum" together hung a box for the whole time limit in round 4 -- bench_support/profile.sh
+# takes them in separate passes):
 #   bash bench_support/jobs/pmc_kernel.sh "<bench args>" "<kernel substring>" "<counters>" name1 name2 ...
 ROOT=$(pwd); export TMPDIR=/tmp
 ARGS="$1"; KERN="$2"; CTRS="$3"; shift 3
