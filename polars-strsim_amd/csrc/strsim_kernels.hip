@@ -298,8 +298,11 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     const uint32_t base = txt.row - lane * 128u; // the wave's 64 rows of 128 bytes
     uint32_t o = 0u, n = 0u;
     // (windows: 32 W bytes of pattern, 32 wtw bytes of text; a lane without a row fetches its column's first bytes)
-    const bool edge = __ballot(has && ((uint64_t)b0 + 32u * (uint32_t)W > totalB || (uint64_t)a0 + 32u * wtw > totalA)) != 0ull ||
-                      totalB < 32u * (uint32_t)W || totalA < 32u * wtw;
+    // (valA / valB and their totals are the LANE's: the symmetric measures take their text from either column, and a lane without a
+    //  row reads its columns' first bytes -- the test covers every lane and its result is uniform: a cooperative fetch with some
+    //  lanes switched off hands out null addresses [r4, found by tests/fuzz_gpu.py: a 32-byte literal against 33..40-byte rows])
+    const bool edge = __ballot((has && ((uint64_t)b0 + 32u * (uint32_t)W > totalB || (uint64_t)a0 + 32u * wtw > totalA)) ||
+                               totalB < 32u * (uint32_t)W || totalA < 32u * wtw) != 0ull;
     if (!edge) {
         // both fetches in flight together; the pattern passes through the rows first, then the text moves in
         const uint32_t pstart = has ? b0 : 0u, tstart = has ? a0 : 0u;

@@ -42,6 +42,8 @@ while time.time() < t_end:
         B = [B[rng.randrange(n)]]
     ao, av = S.pack_strings(A)
     bo, bv = S.pack_strings(B)
+    if os.environ.get("STRSIM_FUZZ_VERBOSE"):  # (a GPU fault kills the process: say what was running)
+        print(f"round {rounds + 1}: {measure} {name} [{lo},{hi}] n={n} literal={side} bytes a={len(av)} b={len(bv)}", flush=True)
     got = ctx.pairs_host(measure, ao, av, bo, bv)
     A2 = A * n if len(A) == 1 else A
     B2 = B * n if len(B) == 1 else B

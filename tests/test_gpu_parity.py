@@ -312,6 +312,22 @@ def test_literal_against_every_row_class(S, ctx, measure):
 
 
 @pytest.mark.parametrize("measure", O.MEASURES)
+def test_literal_of_a_whole_window_against_longer_rows(S, ctx, measure):
+    """A literal of exactly 32 / 64 / 96 / 128 bytes is a column of its own whose windows end where the column ends; against rows of
+    33..128 bytes k_lane_wide takes its text or its pattern from it -- per LANE for the symmetric measures, and the lanes of a
+    round without a row read their columns' first bytes.  (Round 4: the test "does a window reach past its column" was taken per
+    lane, the wave's fetch ran with some lanes switched off and handed out null addresses: found by tests/fuzz_gpu.py.)"""
+    import random
+    rng = random.Random(32)
+    for n, lo, hi in ((7000, 0, 40), (3000, 20, 140), (40, 33, 40)):
+        A = ["".join(rng.choice("ab") for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+        for ll in (31, 32, 33, 64, 96, 128):
+            lit = "".join(rng.choice("ab") for _ in range(ll))
+            assert_bit_exact(gpu(S, ctx, measure, A, [lit]), O.batch_strings(measure, A, [lit], 8), A, [lit], f"{measure} col,lit{ll}")
+            assert_bit_exact(gpu(S, ctx, measure, [lit], A), O.batch_strings(measure, [lit], A, 8), [lit], A, f"{measure} lit{ll},col")
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
 def test_strings_beyond_the_wave_kernel_cap(S, ctx, measure):
     """> 1024-byte strings: finished by the second pass launched from strsim_ctx_synchronize()."""
     import random
