@@ -2,7 +2,7 @@
 # Round-4 evidence run (one gpurun call): counter profiles of the final build first (they write profiles/traffic.json, which the
 # bench lines taken afterwards replay), then the bench lines of every config, the measures, the side benches, the GPU suite.
 OUT=gpurun_out/r4_final; rm -rf $OUT; mkdir -p $OUT
-STEPS=30 WARMUP=10 TRAFFIC_KEY=cfg2:levenshtein:100000000 TRAFFIC_KERNEL=k_lane_stage bash bench_support/profile.sh r4_cfg2 > $OUT/prof_cfg2.txt 2>&1
+STEPS=150 WARMUP=20 TRAFFIC_KEY=cfg2:levenshtein:100000000 TRAFFIC_KERNEL=k_lane_stage bash bench_support/profile.sh r4_cfg2 > $OUT/prof_cfg2.txt 2>&1
 STEPS=8 WARMUP=3 TRAFFIC_KEY=cfg3:jaro_winkler:100000000 TRAFFIC_KERNEL=k_lane_stage+k_lane_wide bash bench_support/profile.sh r4_cfg3 --config cfg3 > $OUT/prof_cfg3.txt 2>&1
 STEPS=3 WARMUP=1 TRAFFIC_KEY=cfg5:levenshtein:10000000 TRAFFIC_KERNEL=k_lane_stage+k_wave_pairs bash bench_support/profile.sh r4_cfg5 --config cfg5 > $OUT/prof_cfg5.txt 2>&1
 cp profiles/traffic.json $OUT/traffic.json
