@@ -404,7 +404,9 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
     if (DO_JARO) {
         // second pass: the k-th flagged character of a against the k-th flagged character of b (ascending positions); they
         // are equal iff bit j_k of Eq(a_{i_k}) is set.  Columns at or beyond la have no flag, so no predicate is needed.
-        uint32_t t = 0u, rest = fb;
+        // [r4] The unequal pairs are COLLECTED as bits of b (every partner is a different bit) and counted once at the end: one
+        // three-input op per column where a compare and an add with carry stood.
+        uint32_t unequal = 0u, rest = fb;
 #pragma unroll
         for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
             if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
@@ -415,11 +417,11 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
                 const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
                 rest ^= jbit;
                 const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
-                t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+                unequal = bitop3<0xF4>(unequal, jbit, Eq);         // unequal | (jbit & ~Eq)
             }
         }
         m_out = popc32(fb);
-        t_out = t;
+        t_out = popc32(unequal);
     }
 }
 

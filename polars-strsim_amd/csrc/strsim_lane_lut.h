@@ -263,7 +263,7 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
     if (DO_JARO) {
         // second pass: the k-th flagged character of a against the k-th flagged character of b (ascending positions); they
         // are equal iff bit j_k of Eq(a_{i_k}) is set.  Columns at or beyond la have no flag, so no predicate is needed.
-        uint32_t tt = 0u, rest = fb;
+        uint32_t unequal = 0u, rest = fb; // (collected as bits of b, counted once: lane_cores32)
         ix = lut_index(t, wa[0]);
         unrolled_until<0, LUT_AHEAD>([&](auto gc) { fetch(gc); return true; });
         unrolled_until<0, NG>([&](auto gc) {
@@ -276,12 +276,12 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
                 const uint32_t on = bit_fill(fa, i);               // a_i was matched
                 const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
                 rest ^= jbit;
-                tt += ((jbit & ~E[g][ii]) != 0u) ? 1u : 0u;
+                unequal = bitop3<0xF4>(unequal, jbit, E[g][ii]);   // unequal | (jbit & ~Eq)
             }
             return true;
         });
         m_out = popc32(fb);
-        t_out = tt;
+        t_out = popc32(unequal);
     }
 }
 

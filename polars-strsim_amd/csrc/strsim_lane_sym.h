@@ -176,7 +176,7 @@ STRSIM_HD void jaro_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32_t lb
             if (i >= bound) lomask = (lomask << 1) | 1u;
         }
     }
-    uint32_t t = 0u, rest = fb;
+    uint32_t unequal = 0u, rest = fb; // (the unequal pairs collected as bits of b, counted once: lane_cores32)
     for (uint32_t i0 = 0; i0 < steps4; i0 += 4u) {
         uint32_t sy[4];
 #pragma unroll
@@ -188,11 +188,11 @@ STRSIM_HD void jaro_sym(const Txt &txt, uint32_t la, uint32_t steps, uint32_t lb
             const uint32_t jbit = rest & (0u - rest) & on;
             rest ^= jbit;
             const uint32_t Eq = eq_sym<NP>(P, lbmask, sy[q]);
-            t += ((jbit & ~Eq) != 0u) ? 1u : 0u;
+            unequal = bitop3<0xF4>(unequal, jbit, Eq); // unequal | (jbit & ~Eq)
         }
     }
     m_out = popc32(fb);
-    t_out = t;
+    t_out = popc32(unequal);
 }
 
 template <int NP, class Txt>
