@@ -378,16 +378,18 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t n
         if ((uint32_t)g >= nb4) return false;
         const uint32_t word = wp[g];
         constexpr int j0 = 4 * g;
-        // the four positions of this dword: flags and SA positions first, so that the four reads are in flight together
-        uint32_t fl[4], ach[4];
+        // the four positions of this dword: flags and SA positions first, so that the four reads are in flight together.  A flag
+        // is kept as a MASK (all ones: b_j was matched): k - mask steps the position, (character ^ byte) & mask is non-zero for
+        // an unequal pair -- seven instructions per position where the compiler made ten of the 0 / 1 form ([r4]).
+        uint32_t flm[4], ach[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            fl[jj] = (fb[j0 >> 5] >> ((j0 & 31) + jj)) & 1u; // b_j was matched
+            flm[jj] = bit_fill(fb[j0 >> 5], (j0 & 31) + jj);
             ach[jj] = sa.get(k);
-            k += fl[jj];
+            k -= flm[jj];
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) t += ach[jj] != ((word >> (8 * jj)) & 0xFFu) ? fl[jj] : 0u;
+        for (int jj = 0; jj < 4; ++jj) t = add_nz(t, bitop3<0x28>(ach[jj], (word >> (8 * jj)) & 0xFFu, flm[jj])); // (a ^ b) & c
         return true;
     });
     m_out = m;
