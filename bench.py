@@ -121,8 +121,33 @@ def plugin_e2e(measure, cfg, rows, name=None):
             "note": "host Arrow views -> host f64 through the plugin C ABI (pack + H2D + kernels + D2H); never `value`"}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks HERE, one process per GPU,
+    as a CHILD `python -m torch.distributed.run` (never an exec of this process; nothing here has touched the GPU yet --
+    torch.cuda.device_count() does not initialise it), relay what the ranks print (rank 0's JSON line) and leave with the child's
+    exit code.  N ranks on fewer than N GPUs are refused here already (the ranks check it again among themselves)."""
+    import socket
+    import subprocess
+    if not a.same_device:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but this node has {have} GPU(s) (one rank per GPU; --same-device --backend gloo is the one-GPU smoke test)")
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher in the environment: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     import torch
     import torch.distributed as dist
     from bench_support import workload as W
@@ -133,8 +158,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit(f"--gpus {a.gpus} needs one process per GPU: python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...")
+    if a.gpus > 1 and world == 1:  # (WORLD_SIZE=1 set by hand; without WORLD_SIZE the ranks were started above)
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE=1: unset it (bench.py then starts the ranks itself) or launch {a.gpus} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if a.same_device:
@@ -271,6 +296,24 @@ def main():
             shipper.drain()
         torch.cuda.synchronize()
 
+    # One-launch calls stay pending until they are retired, and the context's ring holds 32 of them: a caller that never retires
+    # makes strsim_pairs_device synchronise the stream at every wrap -- inside the timed loop.  So the loop keeps a window of
+    # INFLIGHT steps: before step i is enqueued, step i - INFLIGHT (complete by its own event) is retired call by call.
+    INFLIGHT = 8
+    calls_per_step = len(parts) * (1 if fused else len(measures))
+    window = [torch.cuda.Event() for _ in range(INFLIGHT)] if not gather else None
+
+    def run(nsteps):
+        for i in range(nsteps):
+            if window is not None and i >= INFLIGHT:
+                window[i % INFLIGHT].synchronize()
+                for _ in range(calls_per_step):
+                    ctx.retire_oldest()
+            step(i)
+            if window is not None:
+                window[i % INFLIGHT].record(compute_stream)
+        drain()
+
     # Preheat (disclosed in the JSON line): the first 25-40 ms after the GPU goes from idle to this load run ~5-10 % slower
     # (clock ramp), which a short run (--warmup 5 --steps 20 is 35 ms) would measure instead of the steady state a 100 M-row
     # job is in.  One step is timed to size the preheat; every rank runs the same number of steps (the gather is collective).
@@ -286,13 +329,9 @@ def main():
             dist.all_reduce(one, op=dist.ReduceOp.MAX)
         preheat_steps = max(0, min(2000, int(a.preheat_ms * 1e-3 / max(float(one.item()), 1e-6)) + 1))
         preheat_steps += preheat_steps & 1  # (an even count: the output / gather slots alternate with the step index)
-        for i in range(preheat_steps):
-            step(i)
-        drain()
+        run(preheat_steps)
         preheat_steps += 2
-    for i in range(a.warmup):
-        step(i)
-    drain()
+    run(a.warmup)
     ctx.timing(True)
     if shipper is not None:
         shipper.timing_begin()
@@ -301,9 +340,7 @@ def main():
     torch.cuda.synchronize()
     ops0 = ctx.enqueued_ops
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    drain()
+    run(a.steps)
     ops_per_step = (ctx.enqueued_ops - ops0) / max(a.steps, 1)
     if world > 1:
         dist.barrier()
@@ -387,7 +424,13 @@ def main():
             "dtype": "u8/u32 bit-parallel, f64 epilogue", "data": "synthetic",
             "config": {"workload": f"{a.config}: {measure}, {total_rows} rows ({a.scaling} scaling: {rows} on rank 0), lengths "
                                    f"{'U' if law == W.UNIFORM else 'Zipf'}{{{lo}..{hi}}} bytes, a-z, seed {seed}",
-                       "rows_total": total_rows, "rows_rank0": rows, "preheat_steps": preheat_steps, "distributed": distributed,
+                       "rows_total": total_rows, "rows_rank0": rows, "preheat_steps": preheat_steps,
+                       # how the calls were enqueued: one-launch calls (strsim_ctx_set_stream_ordered(ctx, 0), the ABI's opt-in mode:
+                       # a call is its first kernel alone unless the context's last call left slow rows) when nothing is gathered,
+                       # the default stream-ordered mode (every kernel of the chain up front) under the gather
+                       "call_mode": "stream_ordered (ABI default)" if gather else "one_launch (opt-in, strsim_ctx_set_stream_ordered(ctx, 0))",
+                       "calls_in_flight_max": None if gather else INFLIGHT * calls_per_step,
+                       "distributed": distributed,
                        "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,

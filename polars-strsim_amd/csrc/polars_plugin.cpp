@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -813,28 +814,47 @@ unsigned cpu_quota()
     return n;
 }
 
-// plugin calls running in this process right now (an engine calls from several of its threads at once)
-std::atomic<unsigned> g_active_calls{0};
+// Packing threads of one call.  A call from a sequential engine context packs on every CPU the process may use (capped at 32).
+// CallerContext PARALLEL (reference strsim.rs:53) means the engine is already parallel; the reference then computes on the calling
+// thread alone, so as not to oversubscribe the CPUs.  Here such a call may BORROW helper threads from one process-wide budget of
+// half the CPU quota: the permits it holds are taken at its entry and given back when it returns (PackGrant), so however the
+// engine's calls arrive -- staggered or together -- the helpers running at any moment never exceed that half; a call that finds
+// the budget lent out packs on its own thread, as the reference does.  (Round 4 sized the helpers from a one-shot read of a
+// counter of calls in flight: sixteen calls arriving staggered got 16, 10, 8, 6, ... helpers each, about 70 in all.)
+// A lone call in this mode (a group-by of one partition, a streaming batch) packs on up to half the CPUs -- 10 M rows in 13 ms
+// instead of 48-80.  POLARS_STRSIM_PARALLEL_PACK=0 keeps the reference's rule to the letter; POLARS_STRSIM_PACK_THREADS=k caps a
+// call's threads in either mode.
+std::atomic<int> g_helpers_out{0}; // helper threads lent to engine-parallel calls right now
 
-unsigned pack_threads(bool engine_parallel, uint64_t rows)
-{
-    if (rows < 32768) return 1;
-    static const unsigned granted = cpu_quota(); // logical CPUs, capped by the cgroup's CPU quota (containers)
-    unsigned cap = std::min<unsigned>(granted, 32u);
-    if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) cap = std::max(1, atoi(e)); // explicit override, any value
-    if (engine_parallel) {
-        // CallerContext PARALLEL (reference strsim.rs:53): the engine is already parallel, so the reference computes on the calling
-        // thread alone.  Its reason is not to oversubscribe the CPUs -- which a call can see for itself: helper threads only for
-        // the share of the CPUs that the calls in flight right now leave, and never more than half of them (the engine's own
-        // threads are at work too).  A lone call in this mode (a group-by of one partition, a streaming batch) packs on up to
-        // half the CPUs -- 10 M rows in 13 ms instead of 48-80 -- ; sixteen concurrent ones pack on one thread each, as before.
-        // POLARS_STRSIM_PARALLEL_PACK=0 restores the reference's rule to the letter.
+struct PackGrant {
+    unsigned threads = 1; // packing threads of this call, the calling thread included
+    int borrowed = 0;
+    PackGrant(bool engine_parallel, uint64_t rows)
+    {
+        if (rows < 32768) return;
+        static const unsigned granted = cpu_quota(); // logical CPUs, capped by the cgroup's CPU quota (containers)
+        unsigned cap = std::min<unsigned>(granted, 32u);
+        if (const char *e = getenv("POLARS_STRSIM_PACK_THREADS")) cap = (unsigned)std::max(1, atoi(e)); // explicit cap, any value
+        const unsigned want = (unsigned)std::min<uint64_t>(cap, rows / 16384);
+        if (!engine_parallel) { threads = std::max(1u, want); return; }
         static const bool strict = [] { const char *e = getenv("POLARS_STRSIM_PARALLEL_PACK"); return e && atoi(e) == 0; }();
-        const unsigned active = std::max(1u, g_active_calls.load(std::memory_order_relaxed));
-        cap = strict ? 1u : std::max(1u, active == 1u ? cap / 2u : cap / (active + 1u));
+        if (strict || want <= 1u) return;
+        const int budget = (int)std::min<unsigned>(granted, 32u) / 2; // the engine's own threads keep the other half
+        int out = g_helpers_out.load(std::memory_order_relaxed);
+        for (;;) {
+            const int take = std::min<int>((int)want - 1, budget - out);
+            if (take <= 0) return;
+            if (g_helpers_out.compare_exchange_weak(out, out + take, std::memory_order_acq_rel, std::memory_order_relaxed)) {
+                borrowed = take;
+                threads = 1u + (unsigned)take;
+                return;
+            }
+        }
     }
-    return (unsigned)std::min<uint64_t>(cap, rows / 16384);
-}
+    ~PackGrant() { if (borrowed) g_helpers_out.fetch_sub(borrowed, std::memory_order_acq_rel); }
+    PackGrant(const PackGrant &) = delete;
+    PackGrant &operator=(const PackGrant &) = delete;
+};
 
 // pack rows [r0, r1) of `c` into pinned staging (u32 offsets rebased to 0); returns the packed byte count
 uint64_t pack_slice(const Column &c, uint64_t r0, uint64_t r1, Buf &off, Buf &val, unsigned T)
@@ -1383,11 +1403,8 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
     // a NULL literal: the reference unwrap()s and panics (strsim.rs:62,65,87,90); here every row is null
     const bool all_null = (lit[0] && !row_valid(a, 0)) || (lit[1] && !row_valid(b, 0));
 
-    struct Active { // this call counts among the calls in flight for as long as it runs
-        Active() { g_active_calls.fetch_add(1, std::memory_order_relaxed); }
-        ~Active() { g_active_calls.fetch_sub(1, std::memory_order_relaxed); }
-    } active_call;
-    const unsigned T = pack_threads(engine_parallel, n);
+    const PackGrant grant(engine_parallel, n); // (helper threads borrowed for an engine-parallel call go back when it returns)
+    const unsigned T = grant.threads;
     std::vector<PipeTimes> ptimes;
     std::vector<int> devs = plugin_devices();
     if (n != 0 && !all_null) {
@@ -1628,6 +1645,22 @@ POLARS_PLUGIN_API int _strsim_test_validity(SeriesExport *two_series, uint64_t *
         g_plugin_error = "unexpected failure";
     }
     return -1;
+}
+
+// (3) the packing threads of `n_calls` engine-parallel calls of `rows` rows each that are ALL in flight together, entered one after
+// the other (the staggered arrival of an engine's threads): threads_out[i] = what call i packs on.  *helpers_out = helper threads
+// lent out while all of them run; the return value = the same count after all have returned (0).
+POLARS_PLUGIN_API int _strsim_test_pack_grants(int engine_parallel, int n_calls, uint64_t rows, unsigned *threads_out, int *helpers_out)
+{
+    {
+        std::vector<std::unique_ptr<PackGrant>> g;
+        for (int i = 0; i < n_calls; ++i) {
+            g.emplace_back(new PackGrant(engine_parallel != 0, rows));
+            threads_out[i] = g.back()->threads;
+        }
+        *helpers_out = g_helpers_out.load();
+    }
+    return g_helpers_out.load();
 }
 #endif // STRSIM_TEST_HOOKS
 

@@ -52,8 +52,9 @@ struct OutPtrs {
 
 // ------------------------------------------------------------------------------------------------
 // k_lane_wide: one pair per lane for the rows k_lane_stage left behind whose longer string is 33..128 ASCII
-// bytes: masks of W = 1..4 words, as wide as the PATTERN (strsim_lane_wide.h: b for Jaro / Jaro-Winkler, the longer
-// string for the symmetric measures).  A workgroup takes a super of up to 256 mask words (16 384 rows), sorts its flagged
+// bytes: masks of W = 2..4 words, as wide as the PATTERN (strsim_lane_wide.h) -- the LONGER string; the columns walk the shorter
+// one ([r5] for Jaro / Jaro-Winkler too: every measure is symmetric, strsim_lane_core.h; before, a Jaro row with a 100-byte a
+// ran 100 columns).  A workgroup takes a super of up to 256 mask words (16 384 rows), sorts its flagged
 // rows into an LDS list by (W, columns to run) and runs them 64 at a time; finished rows are cleared from the mask,
 // the rest (non-ASCII, longer, empty side) stay for k_lane_utf8 / k_wave_pairs.  With nothing flagged a super costs
 // one coalesced read and one barrier.
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     // 64 rows at a time.  The longer the list, the more alike the rows of a round: cfg3's rounds ran 74 % of their
     // lane-columns on a row that needed them with lists of one span (4 096 rows, 24 keys of 8 / 16 columns), 90 % with the whole
     // super and keys of 4 columns.  A super whose candidates do not fit the list (WIDE_LIST entries) is done span by span.
-    // 4 width classes (masks of 1 .. 4 words: by the pattern; one word = a Jaro row whose a is the long side) x 32 column
+    // 4 width classes (masks of 1 .. 4 words: by the pattern, the longer string -- the one-word class stays empty) x 32 column
     // counts (4 columns each) x 4 quarters of the class's pattern lengths (Jaro's second pass walks the pattern as far as the
     // round's longest one reaches)
     constexpr int NKEY = 512, KPL = NKEY / 64;
@@ -391,7 +392,6 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     __shared__ uint16_t s_list[WIDE_LIST];      // candidate rows (index within the super), sorted by key
     __shared__ uint32_t s_txt[WIDE_WAVES][8 * WIDE_MAXW][64];
 
-    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int RPS = WIDE_ROWS / WIDE_BLOCK; // rows per thread and span in the collection phase
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     __builtin_amdgcn_s_setprio(1);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
             if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0xFFFFu;
             const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
             if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0xFFFFu;
-            const uint32_t steps = SYMMETRIC ? mn : la8, pat = SYMMETRIC ? mx : lb8;
+            const uint32_t steps = mn, pat = mx; // text = the shorter string, pattern = the longer one
             const uint32_t cls = (pat - 1u) >> 5; // masks of cls + 1 words: as wide as the PATTERN is long
             return (cls * 32u + ((steps - 1u) >> 2)) * 4u + (pat - 1u - 32u * cls) / 8u;
         };
@@ -530,24 +530,18 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 const bool has = cur.has;
                 const uint32_t i = cur.i, a0 = cur.a0, la = cur.la, b0 = cur.b0, lb = cur.lb;
                 const uint64_t row = cw0 * 64u + i;
-                const bool swap = SYMMETRIC && la > lb; // symmetric measures walk the shorter string
+                const bool swap = la > lb; // the columns walk the shorter string
                 const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
                 const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
                 const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
-                const bool pat2 = __ballot(has && lp > 32u) != 0ull, pat3 = __ballot(has && lp > 64u) != 0ull;
+                const bool pat3 = __ballot(has && lp > 64u) != 0ull;
                 const bool pat4 = __ballot(has && lp > 96u) != 0ull;
                 const uint32_t wtw = 1u + (__ballot(has && lt > 32u) != 0ull) + (__ballot(has && lt > 64u) != 0ull) +
                                      (__ballot(has && lt > 96u) != 0ull);
                 bool done = false;
                 double res = 0.0;
                 const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
-                bool one_word = false;
-                if constexpr (!SYMMETRIC) { // (the symmetric measures' pattern is the longer string: two words or more)
-                    one_word = !pat2;
-                    if (one_word) wide_round<MEASURE, 1>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
-                }
-                if (one_word) {
-                } else if (!pat3)
+                if (!pat3) // (the pattern is the longer string: two words or more)
                     wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
                 else if (!pat4)
                     wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS);
@@ -626,7 +620,6 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
     __shared__ uint16_t s_symA[WIDE_WAVES][32][64];
     __shared__ uint16_t s_symB[WIDE_WAVES][32][64];
 
-    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int RPT = U8_ROWS / WIDE_BLOCK;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     __builtin_amdgcn_s_setprio(1);
@@ -722,7 +715,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) void k_lane_utf8(const uint32_t *__rest
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
                 if (__ballot(ok) == 0ull) continue;
-                const bool swap = SYMMETRIC && la > lb; // symmetric measures walk the shorter string
+                const bool swap = la > lb; // the columns walk the shorter string (every measure is symmetric: strsim_lane_core.h)
                 const uint16_t *tcol = swap ? colB : colA, *pcol = swap ? colA : colB;
                 const uint32_t lt = ok ? (swap ? lb : la) : 1u, lp = ok ? (swap ? la : lb) : 1u;
                 const uint32_t steps = wave_max_u8(ok ? lt : 0u);
@@ -1690,8 +1683,8 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
     if (la8 == 0u || lb8 == 0u) return 0.0; // also Levenshtein: 1 - max/max
     bool nonascii = false;
     __syncthreads();
-    const uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
-    const uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
+    uint32_t la = wave_decode(valA + a0, la8, sA, nonascii);
+    uint32_t lb = wave_decode(valB + b0, lb8, sB, nonascii);
     double r;
     if (MEASURE == LEVENSHTEIN) {
         // (k_wave_pairs<LEVENSHTEIN> only gets here for an empty side; everything else runs in wave_lev_blocks)
@@ -1705,6 +1698,11 @@ __device__ __forceinline__ double wave_row(const uint8_t *__restrict__ valA, uin
             prefix = ne ? (uint32_t)__builtin_ctzll(ne) : lim;
         }
         uint32_t m, t;
+        // [r5] the matching loop runs once per character of "a": let that be the shorter string (Jaro is symmetric, strsim_lane_core.h)
+        if (la > lb) {
+            uint32_t *const ts = sA; sA = sB; sB = ts;
+            const uint32_t tl = la; la = lb; lb = tl;
+        }
         // bits that vary over both strings decide how many planes the match masks need
         uint32_t o = 0u, n_ = 0xFFFFFFFFu;
         for (uint32_t i = lane; i < la; i += 64u) { o |= sA[i]; n_ &= sA[i]; }
@@ -2222,10 +2220,10 @@ static void launch_lane_t(const LaunchArgs &a)
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;
-    // a column against a literal (strsim_lane_lit.h): the literal is the wave-uniform text, the column is staged -- either side
-    // for the symmetric measures, only a literal a for Jaro / Jaro-Winkler (they walk a)
+    // a column against a literal (strsim_lane_lit.h): the literal is the wave-uniform text, the column is staged -- on either
+    // side, for every measure ([r5] Jaro / Jaro-Winkler included: they are symmetric, strsim_lane_core.h)
     const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
-    const bool lit_path = (M == JARO || M == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
+    const bool lit_path = lit_a || lit_b;
     if (lit_path && !a.no_literal_path) {
         const bool litA = lit_a;
         const uint64_t nlb = (a.n + (LIT_ROWS - 1)) / LIT_ROWS;
@@ -2389,7 +2387,7 @@ int lane_kernel_launches(int measure, const LaunchArgs &a)
 {
     if (measure == 5) return 1;
     const bool lit_a = a.rowsA == 1 && a.rowsB != 1, lit_b = a.rowsB == 1 && a.rowsA != 1;
-    const bool lit_path = (measure == JARO || measure == JARO_WINKLER) ? lit_a : (lit_a || lit_b);
+    const bool lit_path = lit_a || lit_b;
     return (lit_path && !a.no_literal_path) ? 2 : 1; // k_lane_lit + k_publish_lit
 }
 

@@ -29,6 +29,21 @@ namespace strsim {
 
 enum Measure : int { LEVENSHTEIN = 0, JARO = 1, JARO_WINKLER = 2, JACCARD = 3, SORENSEN_DICE = 4 };
 
+// EVERY measure is symmetric in its two strings, bit for bit -- so every kernel is free to choose which string its column
+// loop walks (the "text": the shorter one) and which one is transposed into bit-planes (the "pattern").  For Levenshtein and the
+// multiset measures that is plain.  [r5] For the reference's Jaro (strsim.rs:200-243) it holds too, although its loop walks a and
+// picks the lowest free partner in b:
+//   * an edge (i, j) exists iff a_i == b_j, |i - j| <= bound, i < la, j < lb (`take(b.len() + bound)` and `min(i + bound, lb - 1)`,
+//     :208-210, only cut what those four conditions cut), and bound = max(la, lb) / 2 - 1 (:200) does not care about the order;
+//   * the greedy matching is the same from either side.  Per character (edges only join equal characters): let a1 / b1 be the
+//     lowest position of that character in a / b.  If |a1 - b1| <= bound both loops pair them first (b1 is the lowest candidate
+//     of a1 and vice versa); if b1 < a1 - bound no position of a reaches b1 (they all lie at or above a1), from either side; if
+//     a1 < b1 - bound likewise.  Remove what was decided and repeat: the two loops flag the same positions;
+//   * t zips the flagged characters of both strings in order (:220-237), m / la + m / lb is an IEEE addition, which commutes, and
+//     the common prefix of Jaro-Winkler (:261-266) does not know which string came first.
+// tests/test_oracle_golden.py::test_jaro_is_symmetric_bit_for_bit holds the oracle to it (small alphabets, lengths 0..400); the
+// GPU parity suites compare every kernel against jaro(a, b) as the reference computes it.
+
 // The per-column loops of the cores are fully unrolled and leave at a lane-uniform bound (tmax) that is tested every
 // COLS_PER_TEST columns: a round of 64 pairs runs its longest text rounded up to that (cfg2: 17.5 columns per pair
 // with 4, 16.3 with 2, 13.9 needed).

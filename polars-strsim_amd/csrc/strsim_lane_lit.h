@@ -1,9 +1,7 @@
 // strsim_lane_lit.h -- k_lane_lit<M>: a COLUMN against ONE LITERAL (strsim.rs:48-52, :61-66, :85-92: either side of the
 // expression may be a Utf8 literal that is broadcast over the rows), one pair per lane, for literals and column strings of
 // <= 32 ASCII bytes.  Included by strsim_kernels.hip inside namespace strsim, after strsim_lane_stage.h.
-// Levenshtein, Jaccard and Sorensen-Dice are symmetric, so the literal may be on either side; Jaro and Jaro-Winkler walk a
-// (strsim.rs:200-237), so they come here only when the literal IS a -- a literal b goes through k_lane_stage, sorted by the
-// column's lengths.
+// Every measure is symmetric ([r5] the reference's Jaro included: strsim_lane_core.h), so the literal may be on either side.
 //
 // What a literal buys, in the terms of the issue-cost table of bench_support/micro/op_cost.hip:
 //   * the literal is the TEXT the recurrence walks: every lane runs exactly len(literal) columns -- no sort by column
@@ -62,7 +60,7 @@ __device__ __forceinline__ uint32_t lit_lev_uniform_text(const uint32_t (&wt)[8]
     return lt + popc32(Pl & rows) - popc32(Ml & rows);
 }
 
-// offC / valC: the column; offL / valL: the literal (one row).  Jaro, Jaro-Winkler: the literal is a, the column b.
+// offC / valC: the column; offL / valL: the literal (one row), whichever side of the expression it stood on.
 template <int MEASURE>
 __global__ __launch_bounds__(LIT_BLOCK) __attribute__((amdgpu_waves_per_eu(STRSIM_LIT_WAVES_PER_EU))) void
 k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, const uint32_t *__restrict__ offL,
@@ -274,7 +272,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
                 }
                 if (fast) s_code[LEV ? bb : 0u][LEV ? i : 0u] = (uint16_t)code;
             } else {
-                // text = the literal (for Jaro / Jaro-Winkler it is a), pattern = the column string: exactly litl columns for every
+                // text = the literal, pattern = the column string: exactly litl columns for every
                 // lane, the bit fills of the uniform text on the scalar unit.  The integers as stage_ints packs them; an empty
                 // side is caught by the epilogue's early-outs (strsim.rs:182-186, :288-292, :324-328).
                 uint32_t dist = 0u, m = 0u, t = 0u, isect = 0u;

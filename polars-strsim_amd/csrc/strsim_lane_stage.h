@@ -137,8 +137,8 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // Descriptor of a row, 8 bytes, written in length order by sortB:
 //   x = text window | pattern window << 16: byte index into s_bytes (staging areas of a and b, the literals' copies)
 //   y = text length | pattern length << 8 | row index within the block << 16 | not mine << 31
-// "text" is the string the columns of the bit-parallel cores walk: a, or the shorter one for the symmetric measures
-// when both sides are columns.
+// "text" is the string the columns of the bit-parallel cores walk: the shorter one when both sides are columns ([r5] for
+// Jaro / Jaro-Winkler and the five-output pass too: the reference's greedy matching is symmetric, strsim_lane_core.h).
 constexpr uint32_t STAGE_DEAD = 1u << 31;
 
 // 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7]: nine dwords from the dword-aligned address below (56 LDS
@@ -190,8 +190,9 @@ __device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint3
 
 // All five measures of one pair from one set of bit-planes (BASELINE config 4), as the integers their epilogues need, packed
 // into 64 bits: dist | m << 6 | t << 12 | I << 18 | common prefix << 24 | la << 27 | lb << 33 (all-ones is never produced).
-// Jaro's matching serves Jaro and Jaro-Winkler, the multiset intersection Jaccard and Dice; no role swap (Jaro walks a, so
-// every measure does).  The epilogues run in the store phase (stage_all_epilogues), once per row, on coalesced lanes.
+// Jaro's matching serves Jaro and Jaro-Winkler, the multiset intersection Jaccard and Dice; "la" / "lb" are the lengths of the
+// text and the pattern (the shorter and the longer string: every epilogue is symmetric in them).  The epilogues run in the store
+// phase (stage_all_epilogues), once per row, on coalesced lanes.
 template <int NP, bool USE_LUT>
 __device__ __forceinline__ unsigned long long stage_all_ints(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la,
                                                              const uint32_t (&wb)[8], uint32_t lb, uint32_t tmin, uint32_t tmax)
@@ -236,7 +237,7 @@ __device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, doubl
 }
 
 // One of the other four measures as 32 bits of integers: Jaro / Jaro-Winkler: m | t << 6 | la << 12 | lb << 18 | common
-// prefix << 24; Jaccard / Dice: I | la << 6 | lb << 12 (all-ones is never produced).  text = a, pattern = b.
+// prefix << 24; Jaccard / Dice: I | la << 6 | lb << 12 (all-ones is never produced).  la / lb: text / pattern.
 template <int MEASURE, int NP, bool USE_LUT>
 __device__ __forceinline__ uint32_t stage_ints(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
                                                uint32_t lb, uint32_t tmin, uint32_t tmax)
@@ -326,7 +327,6 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 {
     constexpr bool LEV = MEASURE == LEVENSHTEIN;
     constexpr bool ALL = MEASURE == ALL_MEASURES; // five outputs: outs.p[measure]; else outs.p[0]
-    constexpr bool SYMMETRIC = MEASURE == LEVENSHTEIN || MEASURE == JACCARD || MEASURE == SORENSEN_DICE;
     constexpr int B = STAGE_ROWS, RPT = STAGE_RPT, NBK = STAGE_NBK;
     constexpr int STAGE_CAP = StageGeom<LUT, LONG>::CAP, STAGE_COL = StageGeom<LUT, LONG>::COL;
     constexpr int STAGE_DMA_ITERS = StageGeom<LUT, LONG>::DMA_ITERS;
@@ -616,7 +616,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const bool stA = bcastA || misA + a0 + la8 <= stagedA, stB = bcastB || misB + b0 + lb8 <= stagedB;
                 const bool mine = have && la8 <= 32u && lb8 <= 32u && stA && stB;
                 const uint32_t wa = bcastA ? LIT : misA + a0, wb = bcastB ? LIT + 32u : COLB + misB + b0;
-                const bool swap = SYMMETRIC && !bcastA && !bcastB && la8 > lb8; // symmetric measures walk the shorter string
+                const bool swap = !bcastA && !bcastB && la8 > lb8; // the columns walk the shorter string (every measure is symmetric: strsim_lane_core.h)
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
                 const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
                 skey[q] = key;

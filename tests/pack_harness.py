@@ -36,6 +36,8 @@ def lib():
         L._strsim_test_pack_views.restype = C.c_int
         L._strsim_test_pack_views.argtypes = [C.POINTER(H.SeriesExport), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p,
                                               C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L._strsim_test_pack_grants.restype = C.c_int
+        L._strsim_test_pack_grants.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_int)]
         L._polars_plugin_get_last_error_message.restype = C.c_char_p
         _lib = L
     return _lib
@@ -138,3 +140,12 @@ def validity(a, b, layouts=("vu", "vu"), threads=1, vals=None):
     tail = np.unpackbits(words.view(np.uint8), bitorder="little")[rows.value: ((rows.value + 63) // 64) * 64]
     assert not tail.any()  # bits past the column are zero
     return bits, nulls.value
+
+
+def pack_grants(engine_parallel, n_calls, rows):
+    """Packing threads of n_calls calls in flight together (entered one after the other) -> (threads per call, helper threads
+    lent out while they all run, helper threads lent out after they have all returned)."""
+    t = np.zeros(n_calls, dtype=np.uint32)
+    out = C.c_int()
+    after = lib()._strsim_test_pack_grants(1 if engine_parallel else 0, n_calls, rows, t.ctypes.data, C.byref(out))
+    return [int(x) for x in t], out.value, after

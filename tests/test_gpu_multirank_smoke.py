@@ -48,6 +48,27 @@ def test_two_ranks_ship_and_verify(extra, transport):
     assert [x["rank"] for x in dd["devices"]] == [0, 1] and all(x["cuda_device"] == 0 for x in dd["devices"])
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment: bench.py starts the two ranks itself (a child
+    torch.distributed.run), relays rank 0's JSON line and leaves with the child's exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--rows", "1000000",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "starting 2 ranks" in r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["distributed"]["world_size"] == 2 and d["config"]["gather_verified"] is True
+    assert d["config"]["call_mode"].startswith("stream_ordered")
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_it_starts_any():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--rows", "1000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "but this node has" in (r.stderr + r.stdout)
+
+
 def test_same_device_is_refused_with_rccl():
     """Two ranks on one GPU are a smoke test of the control flow, not a measurement: only with the gloo backend."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--same-device", "--backend", "nccl", "--rows", "1000",

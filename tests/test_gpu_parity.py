@@ -791,8 +791,9 @@ def test_offsets_from_lengths_refuses_rows_that_could_wrap(S, ctx):
 @pytest.mark.parametrize("side", ["a", "b"])
 def test_literal_calls_are_one_launch_too(S, measure, side):
     """A column of short ASCII strings against a literal is k_lane_lit + a one-thread kernel that publishes what it left (two
-    launches instead of six) on a context that expects no slow rows -- Jaro / Jaro-Winkler with a literal b run in k_lane_stage:
-    one launch; a literal the lane kernels cannot take (longer than 32 bytes) is finished at retirement."""
+    launches instead of six) on a context that expects no slow rows -- on either side, for every measure ([r5] Jaro / Jaro-Winkler
+    with a literal b too: they are symmetric); a literal the lane kernels cannot take (longer than 32 bytes) is finished at
+    retirement."""
     import torch
     A, B, cols = _mixed_frame(S, 0)
     dev = torch.device("cuda", 0)
@@ -805,7 +806,7 @@ def test_literal_calls_are_one_launch_too(S, measure, side):
         with S.Context(0, one_launch=True) as ctx:
             before = ctx.enqueued_ops
             out = ctx.pairs_device(measure, *(lcols + cols[:2] if side == "a" else cols[:2] + lcols))
-            assert ctx.enqueued_ops - before == (1 if (measure in ("jaro", "jaro_winkler") and side == "b") else 2)
+            assert ctx.enqueued_ops - before == 2
             ctx.synchronize()
             assert (ctx.last_late_rows == 0) == (len(lit) <= 32)
             exp = O.batch_strings(measure, [lit] * len(A) if side == "a" else A, A if side == "a" else [lit] * len(A), 8)

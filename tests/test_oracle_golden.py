@@ -110,3 +110,36 @@ def test_jaro_winkler_threshold_and_cap():
             capped += 1
     assert below >= 1 and capped >= 1
     assert math.isclose(O.pair("jaro_winkler", "phillips", "philips"), 0.975, abs_tol=1e-12)
+
+
+def test_jaro_is_symmetric_bit_for_bit():
+    """jaro(a, b) == jaro(b, a) and jaro_winkler likewise, to the bit -- the reference's loop walks a and takes the lowest free
+    partner in b (strsim.rs:208-219), but the matching it finds is the same from either side (proof sketch in
+    csrc/strsim_lane_core.h), t zips both flag sequences in order and m / la + m / lb commutes.  The kernels rely on it: they walk the
+    SHORTER string.  Small alphabets and unequal lengths make the matches cross as often as they can."""
+    import random
+    import numpy as np
+    rng = random.Random(20260501)
+    A, B = [], []
+    for alpha, hi, n in (("ab", 12, 20000), ("abc", 40, 20000), ("abcdefghijklmnopqrstuvwxyz", 32, 20000), ("abé日", 70, 5000), ("abcd", 400, 400)):
+        for _ in range(n):
+            a = "".join(rng.choice(alpha) for _ in range(rng.randint(0, hi)))
+            r = rng.random()
+            if r < 0.4:
+                b = "".join(rng.choice(alpha) for _ in range(rng.randint(0, hi)))
+            elif r < 0.7:
+                b = "".join(rng.choice(alpha) for _ in range(rng.randint(0, max(1, hi // 4))))
+            else:
+                s = list(a)
+                for _ in range(rng.randint(1, 4)):
+                    if s and rng.random() < 0.5:
+                        del s[rng.randrange(len(s))]
+                    else:
+                        s.insert(rng.randint(0, len(s)), rng.choice(alpha))
+                b = "".join(s)
+            A.append(a)
+            B.append(b)
+    for m in ("jaro", "jaro_winkler"):
+        x, y = O.batch_strings(m, A, B, 4), O.batch_strings(m, B, A, 4)
+        bad = np.nonzero(x.view(np.uint64) != y.view(np.uint64))[0]
+        assert bad.size == 0, (m, A[bad[0]], B[bad[0]], x[bad[0]], y[bad[0]])

@@ -146,3 +146,42 @@ def test_one_pass_packer(threads):
     B = list(A)
     B[40_000] = "q" * 300
     assert H.pack_onepass(pa.array(B, type=pa.string()), 0, len(B), bytes_per_row=24, threads=threads) is None  # > 255 bytes
+
+
+def test_engine_parallel_calls_borrow_helpers_from_one_bounded_budget():
+    """CallerContext PARALLEL (strsim.rs:53): the reference packs on the calling thread alone so as not to oversubscribe the CPUs.
+    Here such calls may borrow helper threads -- from ONE process-wide budget of half the CPU quota, whatever the order the
+    engine's threads arrive in (sizing each call from a one-shot read of a counter of calls in flight handed sixteen
+    staggered calls about 70 helpers)."""
+    import os
+    quota = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, min(quota, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    budget = min(quota, 32) // 2
+    threads, lent, after = H.pack_grants(True, 16, 10_000_000)
+    assert after == 0                                   # everything borrowed came back
+    assert lent == sum(t - 1 for t in threads) <= budget
+    assert threads[0] == 1 + budget or budget == 0      # a lone call gets the whole budget ...
+    assert all(t == 1 for t in threads[1:])             # ... and the calls that arrive while it runs pack on their own thread
+    # small calls never take helpers; a sequential engine context is not rationed
+    assert H.pack_grants(True, 3, 20_000) == ([1, 1, 1], 0, 0)
+    seq, lent, after = H.pack_grants(False, 3, 10_000_000)
+    assert lent == 0 and after == 0 and all(t == min(quota, 32) for t in seq)
+
+
+def test_engine_parallel_strict_rule_by_environment(monkeypatch):
+    """POLARS_STRSIM_PARALLEL_PACK=0 (read once per process: a fresh interpreter) keeps the reference's rule to the letter."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path[:0] = [%r, %r]; import pack_harness as P; print(H.pack_grants(True, 2, 10_000_000))"
+            % (os.path.join(H.ROOT, "polars-strsim_amd"), os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ, POLARS_STRSIM_PARALLEL_PACK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip().endswith("([1, 1], 0, 0)")
+    env = dict(os.environ, POLARS_STRSIM_PACK_THREADS="3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("([3, 1], 2, 0)"), (r.stdout, r.stderr[-500:])
