@@ -16,6 +16,8 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 dev = torch.device("cuda", 0)
 measure, _, law, lo, hi, seed = W.CONFIGS[cfg]
+if len(sys.argv) > 3:
+    measure = sys.argv[3]
 oa, va, ob, vb, _, _ = W.device_columns(seed, law, lo, hi, 0, rows, dev)
 out = torch.empty(rows, dtype=torch.float64, device=dev)
 st = torch.cuda.Stream()
@@ -37,6 +39,7 @@ b = buf.astype(np.float64)
 names = ["cut + bytes DMA issue", "store", "sortA", "barrier 1", "sortB", "DMA wait + barrier 2", "offsets DMA issue",
          "rounds: windows", "rounds: cores", "barrier G"]
 tot = b[:, 10].mean()
+print("%s %s" % (cfg, measure))
 print("waves %d  cycles per wave %.0f  realtime ticks %.0f  -> clock %.3f GHz, kernel %.1f us" %
       (nw, tot, b[:, 11].mean(), tot / b[:, 11].mean() * 0.1, b[:, 11].mean() / 100.0))
 for k, nme in enumerate(names):

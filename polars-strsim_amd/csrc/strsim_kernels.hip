@@ -133,6 +133,9 @@ struct LdsTxt {
     }
 };
 // Jaro's string of matched characters (strsim_lane_wide.h) overwrites the front of the lane's text
+#ifndef STRSIM_WIDE_ZIP_MATCHES
+#define STRSIM_WIDE_ZIP_MATCHES 0 // 1: Jaro's zip pass may walk the matched characters instead of b (jaro_wide): measured, off -- see DESIGN 3.3 [r5]
+#endif
 struct LdsSa {
     uint32_t row, swz;
     __device__ __forceinline__ uint32_t at(uint32_t k) const { return xad(k, swz, row); }
@@ -145,6 +148,25 @@ struct LdsSa {
     __device__ __forceinline__ uint32_t get(uint32_t k) const
     {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)at(k));
+    }
+    // positions k .. k + 3, k a multiple of 4 (the swizzle permutes whole dwords)
+    __device__ __forceinline__ uint32_t get4(uint32_t k) const
+    {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)at(k));
+    }
+    // Jaro's zip pass over the matched characters (5 + 9 W instructions per match, as far as the wave's largest m) or over
+    // the positions of b (7 per position, nb4 dwords)?  -> 0, or the number of matches to walk.  Uniform.
+    __device__ __forceinline__ uint32_t zip_over_matches(uint32_t m, uint32_t W, uint32_t nb4) const
+    {
+        uint32_t mm = m; // (m <= 128)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mm, d);
+            mm = mm > o ? mm : o;
+        }
+        mm = uniform(mm);
+        const uint32_t k4 = (mm + 3u) & ~3u;
+        return (STRSIM_WIDE_ZIP_MATCHES && k4 != 0u && k4 * (5u + 9u * W) < 28u * nb4) ? k4 : 0u;
     }
 };
 

@@ -359,8 +359,10 @@ STRSIM_HD double epilogue_sorensen_dice(uint64_t isect, uint64_t la, uint64_t lb
 //   * "a_i found a partner" is `cand != 0`, and the lowest candidate goes into the flags with one three-input op.
 // la, lb >= 1; tmin <= la <= tmax, both lane-uniform.  Outputs: dist (edit distance), m / t (Jaro matches, unequal zipped
 // pairs NOT halved), isect (sum of min counts); only those of the cores switched on are written.
+// KEEP_EQ [r5]: Jaro's zip pass takes the match masks of the first pass from registers (one per column walked: up to 32)
+// instead of building them again -- 5 instead of 15 instructions per column of that pass, for kernels that have the registers.
 // ---------------------------------------------------------------------------------------------
-template <int NP, bool DO_LEV, bool DO_JARO, bool DO_ISECT>
+template <int NP, bool DO_LEV, bool DO_JARO, bool DO_ISECT, bool KEEP_EQ = false>
 STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin, uint32_t tmax, uint32_t lb,
                             const uint32_t (&P)[NP], uint32_t &dist, uint32_t &m_out, uint32_t &t_out, uint32_t &isect)
 {
@@ -377,11 +379,13 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
     const uint32_t valid = DO_JARO ? lbmask : 0xFFFFFFFFu;
     // multiset intersection
     uint32_t used = 0u;
+    uint32_t E[(DO_JARO && KEEP_EQ) ? 32 : 1]; // (every index is a compile-time constant: registers)
 #pragma unroll
     for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
         if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
         auto column = [&](int i) {
             const uint32_t Eq = eq_mask<NP>(P, valid, wa[i >> 2], i & 3);
+            if (DO_JARO && KEEP_EQ) E[(DO_JARO && KEEP_EQ) ? i : 0] = Eq; // (a column past the end of a: never looked at, its flag is clear)
             if (DO_LEV) {
                 const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
                 const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
@@ -431,7 +435,8 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
                 const uint32_t on = bit_fill(fa, i);               // a_i was matched
                 const uint32_t jbit = rest & (0u - rest) & on;     // its partner in the zip: lowest remaining flag of b
                 rest ^= jbit;
-                const uint32_t Eq = eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
+                // (the first pass's mask ends at lb; jbit is a flagged position of b, so that makes no difference)
+                const uint32_t Eq = (DO_JARO && KEEP_EQ) ? E[(DO_JARO && KEEP_EQ) ? i : 0] : eq_mask<NP>(P, 0xFFFFFFFFu, wa[i >> 2], i & 3);
                 unequal = bitop3<0xF4>(unequal, jbit, Eq);         // unequal | (jbit & ~Eq)
             }
         }

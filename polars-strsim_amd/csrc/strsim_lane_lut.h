@@ -32,6 +32,9 @@ namespace strsim {
 #define STRSIM_LUT_AHEAD 1 // groups of COLS_PER_TEST columns between a table read and its use
 #endif
 constexpr int LUT_AHEAD = STRSIM_LUT_AHEAD;
+#ifndef STRSIM_JARO_KEEP_EQ
+#define STRSIM_JARO_KEEP_EQ 1 // Jaro's zip pass reads the first pass's match masks from registers instead of the tables again ([r5]: up
+#endif                        // to 32 registers that the four-waves-per-SIMD instantiations have: cfg2 Jaro 51.5 -> 56.6 G pairs/s, five outputs 34.5 -> 37.2)
 
 constexpr int LUT_ENTRIES = 12;               // L: 0..7, M: 8..11
 constexpr int LUT_WAVE_BYTES = LUT_ENTRIES * 256;
@@ -190,7 +193,8 @@ STRSIM_HD uint32_t lev_myers32_lut(const EqLut &t, const uint32_t (&wt)[8], uint
 // ---------------------------------------------------------------------------------------------
 // lane_cores32 (strsim_lane_core.h: Levenshtein recurrence, Jaro's first pass and the multiset intersection in one column
 // loop over the text a, Jaro's zip pass behind it) with table masks, fetched one group of columns ahead.  The zip pass
-// reads the tables again -- two LDS reads and one AND per column where the bit fills rebuilt the mask with ten instructions.
+// takes the first pass's masks from registers ([r5] STRSIM_JARO_KEEP_EQ; rounds 3-4 read the tables again: two LDS reads and
+// one AND per column, where the bit fills had rebuilt the mask with ten instructions).
 // la, lb >= 1; tmin <= la <= tmax, both lane-uniform; `t` holds the tables of THIS pattern (lut_build, valid = ~0).
 // ---------------------------------------------------------------------------------------------
 template <int NP, bool DO_LEV, bool DO_JARO, bool DO_ISECT>
@@ -264,12 +268,16 @@ STRSIM_HD void lane_cores32_lut(const EqLut &t, const uint32_t (&wa)[8], uint32_
         // second pass: the k-th flagged character of a against the k-th flagged character of b (ascending positions); they
         // are equal iff bit j_k of Eq(a_{i_k}) is set.  Columns at or beyond la have no flag, so no predicate is needed.
         uint32_t unequal = 0u, rest = fb; // (collected as bits of b, counted once: lane_cores32)
+#if !STRSIM_JARO_KEEP_EQ
         ix = lut_index(t, wa[0]);
         unrolled_until<0, LUT_AHEAD>([&](auto gc) { fetch(gc); return true; });
+#endif
         unrolled_until<0, NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if ((uint32_t)(CPT * g) >= tmax) return false;
+#if !STRSIM_JARO_KEEP_EQ
             if constexpr (g + LUT_AHEAD < NG) fetch(std::integral_constant<int, g + LUT_AHEAD>{});
+#endif
 #pragma unroll
             for (int ii = 0; ii < CPT; ++ii) {
                 const int i = CPT * g + ii;

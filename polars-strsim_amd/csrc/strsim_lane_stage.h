@@ -48,6 +48,9 @@
 #ifndef STRSIM_STAGE_LUT
 #define STRSIM_STAGE_LUT 0x26 // bit m set: measure m (bit 5: the five-output pass) takes its match masks from per-lane LDS tables
 #endif                       //   (strsim_lane_lut.h) instead of bit fills.  Default: Jaro, Jaro-Winkler, the five-output pass.
+#ifndef STRSIM_JARO_KEEP_EQ_FILLS
+#define STRSIM_JARO_KEEP_EQ_FILLS 1 // the bit-fill form of Jaro's cores (the long-row geometry) keeps the first pass's masks for the zip pass too
+#endif
 #ifndef STRSIM_STAGE_RANGE_MAX
 #define STRSIM_STAGE_RANGE_MAX 64   // chunks of 64 rows a workgroup takes from the device-wide counter at a time, at most
 #endif
@@ -251,7 +254,7 @@ __device__ __forceinline__ uint32_t stage_ints(const EqLut &lut, const uint32_t 
     if (USE_LUT) lut_build<NP>(tb, P, 0xFFFFFFFFu);
     if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         if (USE_LUT) lane_cores32_lut<NP, false, true, false>(tb, wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
-        else lane_cores32<NP, false, true, false>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect);
+        else lane_cores32<NP, false, true, false, STRSIM_JARO_KEEP_EQ_FILLS != 0>(wa, la1, tmin, tmax, lb1, P, dist, m, t, isect); // (the long-row geometry: four waves per SIMD too)
         const uint32_t pre = MEASURE == JARO_WINKLER ? common_prefix4(wa[0], la1, wb[0], lb1) : 0u;
         return m | (t << 6) | (la << 12) | (lb << 18) | (pre << 24);
     }

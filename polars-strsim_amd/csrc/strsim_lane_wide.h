@@ -316,7 +316,8 @@ STRSIM_HD uint32_t lev_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_
 // LDS (there are never more matches than columns walked, and a group's four characters are in a register before its columns
 // run) --, and the second pass walks b: the k-th flagged b_j against SA[k] (strsim.rs:222-233 zips exactly these two
 // sequences; `put` may ignore `hit`: a character stored at k without a match is overwritten by the next match, k not having
-// moved).  Rounds 1-2 walked a again and rebuilt every column's match mask to test one bit of it: 9 + 9 W instructions
+// moved; `get4(k)`, k a multiple of 4, reads positions k .. k + 3 as one dword; `zip_over_matches(m, W, nb4)` -> 0, or the
+// wave's largest m when the zip pass should walk SA instead of b: see below).  Rounds 1-2 walked a again and rebuilt every column's match mask to test one bit of it: 9 + 9 W instructions
 // per column of a against about ten per position of b here, and the flags of a (kept in LDS between the passes) are gone.
 // ---------------------------------------------------------------------------------------------
 template <int NP, int W, class Txt, class Sa>
@@ -371,6 +372,39 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t n
             left -= 1u;
             column(c4, ii, 4u * g + (uint32_t)ii, dead, std::true_type{});
         }
+    }
+    // [r5] The zip pass, one of two ways -- the wave decides (sa.zip_over_matches: uniform):
+    //   * over the MATCHED characters of a (SA[0 .. m)): the k-th one against the lowest flag of b not used yet, equal iff that
+    //     bit is in the character's match mask (what the 32-byte cores do) -- 5 + 9 W instructions per match;
+    //   * over the positions of b (below): 7 instructions per position.
+    // The text is the shorter string and m <= its length, so the first way wins whenever the pattern is much longer than the text:
+    // half of cfg3's rows of 33..128 bytes are an independent pair with a short side of a dozen characters (7 x 65 positions
+    // against 23 x 12 matches).  Lanes with fewer matches than the wave's maximum have no flag left: their steps change nothing.
+    const uint32_t kmax = sa.zip_over_matches(m, (uint32_t)W, nb4);
+    if (kmax != 0u) {
+        uint32_t all[W], rest[W], uneq[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { all[w] = 0xFFFFFFFFu; rest[w] = fb[w]; uneq[w] = 0u; }
+        for (uint32_t k0 = 0u; k0 < kmax; k0 += 4u) {
+            const uint32_t c4 = sa.get4(k0); // SA[k0 .. k0 + 3]
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                uint32_t Eq[W], d[W];
+                eq_wide<NP, W>(P, all, c4, jj, Eq);
+                minus1_wide(rest, d);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uneq[w] |= bitop3<0x10>(rest[w], d[w], Eq[w]); // lowest flag left (rest & ~(rest - 1)), if not in Eq
+                    rest[w] &= d[w];                                // ... is used up
+                }
+            }
+        }
+        uint32_t tt = 0u;
+#pragma unroll
+        for (int w = 0; w < W; ++w) tt += popc32(uneq[w]);
+        m_out = m;
+        t_out = tt;
+        return;
     }
     uint32_t t = 0u, k = 0u;
     unrolled_until<0, 8 * W>([&](auto gc) {

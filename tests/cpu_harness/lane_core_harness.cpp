@@ -96,6 +96,10 @@ extern "C" int harness_cores32(const uint8_t *a, uint32_t la, const uint8_t *b, 
         lane_cores32<5, true, false, false>(wa, la, tmin, tmax, lb, P, d1, x, x, x);
         lane_cores32<5, false, true, false>(wa, la, tmin, tmax, lb, P, x, m1, t1, x);
         lane_cores32<5, false, false, true>(wa, la, tmin, tmax, lb, P, x, x, x, is1);
+        uint32_t mk = 0, tk = 0, ma = 0, ta_ = 0, da = 0, ia = 0; // (KEEP_EQ: the zip pass on the first pass's masks)
+        lane_cores32<5, false, true, false, true>(wa, la, tmin, tmax, lb, P, x, mk, tk, x);
+        lane_cores32<5, true, true, true, true>(wa, la, tmin, tmax, lb, P, da, ma, ta_, ia);
+        if (mk != m || tk != t || ma != m || ta_ != t || da != d || ia != is) return 6;
     } else {
         uint32_t P[7];
         build_planes<7>(wb, P);
@@ -103,6 +107,9 @@ extern "C" int harness_cores32(const uint8_t *a, uint32_t la, const uint8_t *b, 
         lane_cores32<7, true, false, false>(wa, la, tmin, tmax, lb, P, d1, x, x, x);
         lane_cores32<7, false, true, false>(wa, la, tmin, tmax, lb, P, x, m1, t1, x);
         lane_cores32<7, false, false, true>(wa, la, tmin, tmax, lb, P, x, x, x, is1);
+        uint32_t mk = 0, tk = 0;
+        lane_cores32<7, false, true, false, true>(wa, la, tmin, tmax, lb, P, x, mk, tk, x);
+        if (mk != m || tk != t) return 6;
     }
     out[0] = d; out[1] = m; out[2] = t; out[3] = is;
     if (d1 != d) return 1;
@@ -160,13 +167,28 @@ extern "C" int harness_check_planes(const uint8_t *bytes32)
 // ---- wide (W-word) cores -------------------------------------------------------------------------
 struct ArrTxt { const uint32_t *w; uint32_t operator()(uint32_t g) const { return w[g]; } };
 // Jaro's string of matched characters overwrites the front of the text, as on the GPU (the text column in LDS)
+// How Jaro's zip pass runs (jaro_wide: a wave-uniform choice on the GPU): 0 = over the positions of b, 1 = over the matched
+// characters as far as the lane's own m (rounded up to 4) + g_zip_slack more (the wave's largest m is some other lane's),
+// 2 = the kernel's rule applied to this lane alone.  Set by harness_set_zip_mode().
+static int g_zip_mode = 2;
+static uint32_t g_zip_slack = 0;
+extern "C" void harness_set_zip_mode(int mode, uint32_t slack) { g_zip_mode = mode; g_zip_slack = slack & ~3u; }
 struct ArrSa {
     uint8_t *bytes;
+    uint32_t cap; // bytes of the text buffer SA lives in (the GPU: 128 per lane)
     void put(uint32_t k, uint32_t c, uint32_t) const { bytes[k] = (uint8_t)c; } // unconditional, as on the GPU
     uint32_t get(uint32_t k) const { return bytes[k]; }
+    uint32_t get4(uint32_t k) const { uint32_t v; std::memcpy(&v, bytes + k, 4); return v; }
+    uint32_t zip_over_matches(uint32_t m, uint32_t W, uint32_t nb4) const
+    {
+        uint32_t k4 = (m + 3u) & ~3u;
+        if (g_zip_mode == 0) return 0u;
+        if (g_zip_mode == 1) { k4 = std::min(k4 + g_zip_slack, cap); return k4 ? k4 : 4u; }
+        return (k4 != 0u && k4 * (5u + 9u * W) < 28u * nb4) ? k4 : 0u;
+    }
 };
 
-template <int M, int NP, int W>
+template <int M, int NP, int W, uint32_t TCAP = 32u * W>
 static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W], uint32_t lb, uint32_t b0w)
 {
     const uint32_t ng4 = (la + 3u) / 4u;
@@ -175,7 +197,7 @@ static double run_wide_np(uint32_t *ta, uint32_t la, const uint32_t (&wp)[8 * W]
     const uint32_t a0w = ta[0];
     // (gfull: any value up to la / 4; the kernel passes the wave's minimum -- sweep it through a few)
     const uint32_t gfull = (la / 4u) * ((la ^ lb) & 3u) / 3u;
-    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, nb4, a0w, b0w, ArrSa{reinterpret_cast<uint8_t *>(ta)});
+    return lane_wide_result<M, NP, W>(ArrTxt{ta}, la, gfull, ng4, wp, lb, nb4, a0w, b0w, ArrSa{reinterpret_cast<uint8_t *>(ta), TCAP});
 }
 
 template <int M, int W>
@@ -244,9 +266,9 @@ static double run_wide_tp(const uint8_t *a, uint32_t la, const uint8_t *b, uint3
     uint32_t n8 = n & (n >> 16); n8 &= n8 >> 8;
     const int np = force_np ? force_np : planes_needed((o8 ^ n8) & 0xFFu);
     switch (np) {
-    case 5: return run_wide_np<M, 5, W>(ta, la, wp, lb, b0w);
-    case 6: return run_wide_np<M, 6, W>(ta, la, wp, lb, b0w);
-    default: return run_wide_np<M, 7, W>(ta, la, wp, lb, b0w);
+    case 5: return run_wide_np<M, 5, W, 128u>(ta, la, wp, lb, b0w);
+    case 6: return run_wide_np<M, 6, W, 128u>(ta, la, wp, lb, b0w);
+    default: return run_wide_np<M, 7, W, 128u>(ta, la, wp, lb, b0w);
     }
 }
 

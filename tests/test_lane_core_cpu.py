@@ -36,6 +36,8 @@ def harness():
     L.harness_lane_pair_wide_tp.restype = C.c_double
     L.harness_lane_pair_wide_tp.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_sym.restype = C.c_double
+    L.harness_set_zip_mode.restype = None
+    L.harness_set_zip_mode.argtypes = [C.c_int, C.c_uint32]
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
     L.harness_lev_snap.restype = C.c_uint32
     L.harness_lev_snap.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
@@ -358,3 +360,38 @@ def test_utf8_decode_lane(harness, fill):
                     o |= cp
                     a &= cp
                 assert flags[1] & 0xFFFF == o and flags[2] == a, (s, hex(flags[1]), hex(flags[2]))
+
+
+@pytest.mark.parametrize("measure", ["jaro", "jaro_winkler"])
+@pytest.mark.parametrize("mode,slack", [(0, 0), (1, 0), (1, 8), (1, 128), (2, 0)])
+def test_wide_jaro_zip_pass_over_b_or_over_the_matches(harness, measure, mode, slack):
+    """jaro_wide's zip pass ([r5]): over the positions of b, or over the matched characters of a against the lowest flag of b not
+    used yet -- the wave picks one (the text is the shorter string, so the second way wins when the pattern is much longer).  Both
+    forms, the second one also as far as a LARGER m than the lane's own (the wave's maximum is some other lane's), and the
+    kernel's own rule, over every width and text / pattern length class, crossing matches included (small alphabets)."""
+    rng = random.Random(4200 + mode + slack)
+    harness.harness_set_zip_mode(mode, slack)
+    try:
+        for W in (1, 2, 3, 4):
+            for alphabet in (b"ab", b"abcd", b"abcdefghijklmnopqrstuvwxyz"):
+                for _ in range(120):
+                    lb = rng.randint(max(1, 32 * (W - 1) + 1), 32 * W)
+                    la = rng.choice([rng.randint(1, 12), rng.randint(1, lb), rng.randint(1, 128)])
+                    a = bytes(rng.choice(alphabet) for _ in range(la))
+                    r = rng.random()
+                    if r < 0.4:
+                        b = bytes(rng.choice(alphabet) for _ in range(lb))
+                    elif r < 0.7:
+                        b = bytes(rng.choice(a) for _ in range(lb))
+                    else:  # a inside b, some of it in another order
+                        s_ = list(a[:lb]) + [rng.choice(alphabet) for _ in range(max(0, lb - la))]
+                        for _k in range(4):
+                            i, j = rng.randrange(lb), rng.randrange(lb)
+                            s_[i], s_[j] = s_[j], s_[i]
+                        b = bytes(s_)
+                    exp = O.pair(measure, a, b)
+                    for force, fill in ((0, alphabet[0]), (7, 0)):
+                        got = harness.harness_lane_pair_wide_tp(O.MEASURE_ID[measure], W, a, la, b, lb, force, fill)
+                        assert bits(got) == bits(exp), (measure, W, mode, slack, a, b, got, exp)
+    finally:
+        harness.harness_set_zip_mode(2, 0)
