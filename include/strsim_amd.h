@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010004u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2 */
+#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -55,7 +55,9 @@ typedef enum strsim_status {
     STRSIM_ERR_HIP         = 4, /* a HIP runtime call failed (message has the detail) */
     STRSIM_ERR_OOM         = 5,
     STRSIM_ERR_DTYPE       = 6, /* plugin ABI: input is not a string column (reference `.str()?`, strsim.rs:46-47) */
-    STRSIM_ERR_INTERNAL    = 7
+    STRSIM_ERR_INTERNAL    = 7,
+    STRSIM_ERR_EARLIER_CALL = 8 /* strsim_pairs_device*: retiring EARLIER pending calls at a wrap of the context's ring of 32 failed
+                                   (message has the detail); THIS call was not enqueued and none of its buffers was touched */
 } strsim_status_t;
 
 typedef struct strsim_ctx strsim_ctx_t; /* one device + one stream + its workspace; not thread-safe: one ctx per thread */
@@ -116,7 +118,8 @@ STRSIM_API void *strsim_ctx_stream(strsim_ctx_t *ctx);
  * until it is retired, so a caller that keeps k calls in flight holds k of them.  The library never retires a call the
  * caller has not asked it to, except when more than 32 calls are in flight on one context: then everything pending is
  * retired inside strsim_pairs_device (a stream synchronise) and what that finished late is added to the next
- * retirement's strsim_ctx_last_late_rows().
+ * retirement's strsim_ctx_last_late_rows().  If retiring them fails there, the error is THEIRS: the call returns
+ * STRSIM_ERR_EARLIER_CALL and has not been enqueued (ABI 1.5; before, it returned the earlier call's own code).
  */
 STRSIM_API int strsim_pairs_device(strsim_ctx_t *ctx, int measure,
                         const uint32_t *a_offsets, const uint8_t *a_values, uint64_t a_rows,
@@ -196,6 +199,15 @@ STRSIM_API int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *len
  * hand a String column over with a streaming copy instead of a gather. */
 STRSIM_API int strsim_column_from_views(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values,
                                         uint32_t *offsets, uint8_t *values);
+/* The same with the extents stated (ABI 1.5): `long_values` holds long_bytes bytes, `values` has room for values_bytes.  A slot
+ * whose string would be read from outside long_values (or whose long_values is NULL), or written outside values -- a malformed
+ * column: the slots are the host's to get right -- is NOT copied (its offsets are still written) and counted in *malformed, a
+ * u32 on the device that the caller has zeroed (NULL: not counted): a bad slot cannot fault the GPU.  Sums of lengths beyond
+ * 2^32 - 1 put every later row out of range instead of wrapping.  strsim_column_from_views() is this call with the extents
+ * "not stated" (a NULL long_values still skips every slot beyond 12 bytes). */
+STRSIM_API int strsim_column_from_views_bounded(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values,
+                                                uint64_t long_bytes, uint32_t *offsets, uint8_t *values, uint64_t values_bytes,
+                                                uint32_t *malformed);
 
 /* Close the gaps between up to STRSIM_COMPACT_MAX_SEGMENTS byte segments on the device, one launch on the context's stream:
  * dst[dst_off[k] .. + bytes[k]) = src[src_off[k] .. + bytes[k]) for k < nseg; src and dst are distinct device buffers, the three

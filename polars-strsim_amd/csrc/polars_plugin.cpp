@@ -173,6 +173,7 @@ void pack_range(const Column &c, uint64_t r0, uint64_t r1, uint32_t *off, uint64
                     memcpy(&bi, v[i].rest + 4, 4);
                     memcpy(&bo, v[i].rest + 8, 4);
                     if (!inl && (int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+                    if (!inl && sizes && (int64_t)bo + (int64_t)len > sizes[bi]) fail("Utf8View string reaches past its data buffer");
                     const uint32_t bsel = inl ? 0u : bi;
                     const uint8_t *data = nvar > 0 ? static_cast<const uint8_t *>(a->buffers[2 + bsel]) : nullptr;
                     const uint8_t *src = inl ? v[i].rest : data + bo;
@@ -257,6 +258,7 @@ uint64_t pack_range_onepass(const Column &c, uint64_t r0, uint64_t r1, uint64_t 
             memcpy(&bi, v[i].rest + 4, 4);
             memcpy(&bo, v[i].rest + 8, 4);
             if (!inl && (int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+            if (!inl && sizes && (int64_t)bo + (int64_t)len > sizes[bi]) fail("Utf8View string reaches past its data buffer");
             const uint32_t bsel = inl ? 0u : bi;
             const uint8_t *data = nvar > 0 ? static_cast<const uint8_t *>(a->buffers[2 + bsel]) : nullptr;
             const uint8_t *src = inl ? v[i].rest : data + bo;
@@ -318,6 +320,7 @@ uint64_t views_range(const Column &c, uint64_t r0, uint64_t r1, View *vout, uint
                     memcpy(&bi, v[i].rest + 4, 4);
                     memcpy(&bo, v[i].rest + 8, 4);
                     if ((int64_t)bi >= nvar) fail("Utf8View buffer index out of range");
+                    if (sizes && (int64_t)bo + (int64_t)len > sizes[bi]) fail("Utf8View string reaches past its data buffer"); // (only the index was checked)
                     if (pos + len > limit) return ~0ull;
                     memcpy(lng + pos, static_cast<const uint8_t *>(a->buffers[2 + bi]) + bo, len);
                     View patched = v[i];
@@ -1163,8 +1166,9 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
                 sl.d_long[s].reserve(sl.long_span[s] + 64);
                 HIP_OR_FAIL(hipMemcpyAsync(sl.d_views[s].p, sl.h_views[s].p, sl.rows * sizeof(View), hipMemcpyHostToDevice, stream));
                 if (sl.long_span[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_long[s].p, sl.h_long[s].p, sl.long_span[s], hipMemcpyHostToDevice, stream));
-                if (strsim_column_from_views(ctx, sl.d_views[s].p, sl.rows, static_cast<const uint8_t *>(sl.d_long[s].p),
-                                             static_cast<uint32_t *>(sl.d_off[s].p), static_cast<uint8_t *>(sl.d_val[s].p)) != STRSIM_OK)
+                if (strsim_column_from_views_bounded(ctx, sl.d_views[s].p, sl.rows, static_cast<const uint8_t *>(sl.d_long[s].p), sl.long_span[s],
+                                                     static_cast<uint32_t *>(sl.d_off[s].p), static_cast<uint8_t *>(sl.d_val[s].p),
+                                                     sl.bytes[s] + 64, nullptr) != STRSIM_OK)
                     fail(strsim_last_error_message());
                 doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
                 dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);

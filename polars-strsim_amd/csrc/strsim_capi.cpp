@@ -452,7 +452,11 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         rc = ctx_drain(c);
         c->carry_late_rows += c->last_late_rows;
         c->carry_long_rows += c->last_long_rows;
-        if (rc) return rc;
+        if (rc) { //  the failure belongs to an earlier call: say so, with a code of its own -- this call was not enqueued
+            const std::string why = strsim_last_error_message();
+            set_error("strsim_pairs_device: retiring earlier pending calls at the wrap of the ring failed (this call was not enqueued): %s", why.c_str());
+            return STRSIM_ERR_EARLIER_CALL;
+        }
     }
     const uint64_t nchunks = (n + 63) >> 6;
     // One launch (the lane kernel alone, the rest at retirement if it turns out to be needed) when the caller has opted in and the
@@ -529,10 +533,17 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         const uint32_t left = *reinterpret_cast<volatile uint32_t *>(&c->status_host[slot].lane_left);
         if (getenv("STRSIM_TRACE")) fprintf(stderr, "[strsim] eager call: %llu rows, %u left behind the lane kernel\n", (unsigned long long)n, left);
         if (left == 0u) {
-            c->last_wave_rows = 0;
-            c->last_long_rows = 0;
-            c->last_late_rows = 0;
-            return STRSIM_OK; // nothing pending: strsim_ctx_synchronize() has nothing to retire for this call
+            // nothing pending FOR THIS CALL: strsim_ctx_synchronize() has nothing to retire for it.  The last_* counters describe
+            // the last retirement; they are only reset when no other call of this context is still pending (a caller
+            // with one-launch calls in flight that copied results out early still has to see their late rows)
+            bool others = false;
+            for (int s2 = 0; s2 < strsim_ctx::RING; ++s2) others = others || c->slot_pending[s2];
+            if (!others) {
+                c->last_wave_rows = 0;
+                c->last_long_rows = 0;
+                c->last_late_rows = 0;
+            }
+            return STRSIM_OK;
         }
         la.publish_host = nullptr;
         e0 = launch_slow_only(measure, la);

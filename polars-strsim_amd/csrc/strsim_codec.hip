@@ -342,60 +342,73 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view_block_sums(const uint4 *_
 {
     __shared__ uint32_t s_part[VIEW_THREADS / 64];
     const uint64_t r0 = (uint64_t)blockIdx.x * VIEW_ROWS;
+    // (sums SATURATE at 2^32 - 1: a malformed slot with an absurd length must not wrap a later row's offset back into range)
+    auto sat_add = [](uint32_t a, uint32_t b) { const uint32_t c = a + b; return c < a ? 0xFFFFFFFFu : c; };
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < VIEW_STRIPS; ++k) {
         const uint64_t r = r0 + (uint64_t)k * VIEW_THREADS + threadIdx.x;
-        if (r < rows) mine += reinterpret_cast<const uint32_t *>(views + r)[0];
+        if (r < rows) mine = sat_add(mine, reinterpret_cast<const uint32_t *>(views + r)[0]);
     }
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    for (int d = 32; d >= 1; d >>= 1) mine = sat_add(mine, (uint32_t)__shfl_xor((int)mine, d));
     if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (int w = 0; w < VIEW_THREADS / 64; ++w) tot += s_part[w];
+        for (int w = 0; w < VIEW_THREADS / 64; ++w) tot = sat_add(tot, s_part[w]);
         sums[blockIdx.x] = tot;
     }
 }
 
+// long_bytes / values_bytes: the extents of `longs` and `values` (~0: not stated by the caller); a row whose bytes would come from
+// outside `longs` or land outside `values` is NOT copied and counted in *bad (if given): a malformed slot cannot fault the GPU.
 __global__ __launch_bounds__(VIEW_THREADS) void k_view_column(const uint4 *__restrict__ views, uint64_t rows, const uint8_t *__restrict__ longs,
-                                                             const uint32_t *__restrict__ sums, uint32_t *__restrict__ off,
-                                                             uint8_t *__restrict__ values)
+                                                             uint64_t long_bytes, const uint32_t *__restrict__ sums, uint32_t *__restrict__ off,
+                                                             uint8_t *__restrict__ values, uint64_t values_bytes, uint32_t *__restrict__ bad)
 {
     typedef uint32_t u32_u __attribute__((aligned(1)));
     typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
-    __shared__ uint32_t s_part[VIEW_THREADS / 64];
-    __shared__ uint32_t s_wave[VIEW_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t r0 = (uint64_t)blockIdx.x * VIEW_ROWS;
-    // bytes in front of this block
-    uint32_t mine = 0;
+    // bytes in front of this block.  The prefix in 64 bits (the 32-bit running offset was unchecked): a malformed slot with an absurd length -- or a
+    // block sum that saturated -- puts every later row beyond 32-bit offsets, i.e. out of range below, instead of wrapping it back in.
+    __shared__ unsigned long long s_part64[VIEW_THREADS / 64], s_wave64[VIEW_THREADS / 64];
+    unsigned long long mine = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += VIEW_THREADS) mine += sums[b];
-    uint32_t run = block_sum(mine, s_part); // (block_sum is written for LEN_THREADS == VIEW_THREADS)
-    static_assert(VIEW_THREADS == LEN_THREADS, "block_sum");
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0u) s_part64[wv] = mine;
+    __syncthreads();
+    unsigned long long run = 0;
+    for (int w = 0; w < VIEW_THREADS / 64; ++w) run += s_part64[w];
+    const unsigned long long cap = values_bytes < (1ull << 32) ? values_bytes : (1ull << 32); // (offsets are 32 bits)
     if (blockIdx.x == 0 && tid == 0) off[0] = 0u;
 #pragma unroll 1
     for (int k = 0; k < VIEW_STRIPS; ++k) {
         const uint64_t r = r0 + (uint64_t)k * VIEW_THREADS + tid;
         const uint4 v = r < rows ? views[r] : make_uint4(0u, 0u, 0u, 0u);
         const uint32_t len = v.x;
-        uint32_t inc = len;
+        unsigned long long inc = len;
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d);
+            const unsigned long long up = __shfl_up(inc, d);
             if (lane >= (uint32_t)d) inc += up;
         }
-        if (lane == 63u) s_wave[wv] = inc;
+        if (lane == 63u) s_wave64[wv] = inc;
         __syncthreads();
-        uint32_t at = run + inc - len;
-        uint32_t strip = 0;
+        unsigned long long at = run + inc - len, strip = 0;
         for (uint32_t w = 0; w < (uint32_t)(VIEW_THREADS / 64); ++w) {
-            if (w < wv) at += s_wave[w];
-            strip += s_wave[w];
+            if (w < wv) at += s_wave64[w];
+            strip += s_wave64[w];
         }
         __syncthreads();
         run += strip;
         if (r < rows) {
-            off[r + 1] = at + len;
+            off[r + 1] = (uint32_t)(at + len);
+            const bool in_values = at + len <= cap;
+            const bool in_longs = len <= 12u || (longs != nullptr && (uint64_t)v.w + len <= long_bytes);
+            if (!(in_values && in_longs)) {
+                if (bad) atomicAdd(bad, 1u);
+                continue;
+            }
             uint8_t *__restrict__ const dst = values + at;
             if (len <= 12u) { // the string is in the view: whole dwords, then the tail byte by byte
                 if (len >= 4u) *reinterpret_cast<u32_u *>(dst) = v.y;
@@ -591,7 +604,15 @@ int strsim_offsets_from_lengths(strsim_ctx_t *ctx, const uint8_t *lengths, uint6
 int strsim_column_from_views(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values, uint32_t *offsets,
                              uint8_t *values)
 {
+    // (extents not stated: a NULL long_values still makes every slot beyond 12 bytes "out of range" -- skipped, never dereferenced)
+    return strsim_column_from_views_bounded(ctx, views, rows, long_values, long_values ? ~0ull : 0ull, offsets, values, ~0ull, nullptr);
+}
+
+int strsim_column_from_views_bounded(strsim_ctx_t *ctx, const void *views, uint64_t rows, const uint8_t *long_values, uint64_t long_bytes,
+                                     uint32_t *offsets, uint8_t *values, uint64_t values_bytes, uint32_t *malformed)
+{
     if (!ctx || !offsets || (rows && (!views || !values))) { set_error("strsim_column_from_views: NULL argument"); return STRSIM_ERR_ARG; }
+    if (!long_values) long_bytes = 0;
     const uint64_t nblk = (rows + VIEW_ROWS - 1) / VIEW_ROWS;
     if (nblk > strsim::SCAN_WS_WORDS) {
         set_error("strsim_column_from_views: %llu rows in one call; at most %llu", (unsigned long long)rows,
@@ -609,7 +630,8 @@ int strsim_column_from_views(strsim_ctx_t *ctx, const void *views, uint64_t rows
     if (rc) return rc;
     const uint4 *v = static_cast<const uint4 *>(views);
     hipLaunchKernelGGL(k_view_block_sums, dim3((unsigned)nblk), dim3(VIEW_THREADS), 0, st, v, rows, sums);
-    hipLaunchKernelGGL(k_view_column, dim3((unsigned)nblk), dim3(VIEW_THREADS), 0, st, v, rows, long_values, sums, offsets, values);
+    hipLaunchKernelGGL(k_view_column, dim3((unsigned)nblk), dim3(VIEW_THREADS), 0, st, v, rows, long_values, long_bytes, sums, offsets, values,
+                       values_bytes, malformed);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

@@ -122,7 +122,8 @@ __device__ __forceinline__ uint32_t xad_s(uint32_t a, uint32_t b, uint32_t c) //
 }
 struct LdsTxt {
     uint32_t row, swz;
-    __device__ __forceinline__ uint32_t at(uint32_t g) const { return xad_s(g << 2, swz, row); } // (g: uniform)
+    // g: the text dword, the same in every lane (loop counters bounded by wave maxima) -- xad_s takes it from a scalar register
+    __device__ __forceinline__ uint32_t at(uint32_t g) const { return xad_s(wave_uniform(g << 2), swz, row); }
     __device__ __forceinline__ uint32_t operator()(uint32_t g) const
     {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)at(g));

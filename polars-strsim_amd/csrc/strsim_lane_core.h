@@ -68,6 +68,19 @@ STRSIM_HD void unrolled_until(F &&f)
 }
 
 
+// A value the caller KNOWS to be the same in every lane of the wave, made so for the compiler too (v_readfirstlane; folded away
+// when the value already lives in a scalar register).  Operands handed to inline asm through an "s" constraint go through this:
+// should a future caller pass a divergent value, every lane visibly gets lane 0's -- instead of the compiler inserting the same
+// readfirstlane silently.
+STRSIM_HD uint32_t wave_uniform(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+
 STRSIM_HD uint32_t popc32(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -355,7 +355,7 @@ STRSIM_HD void jaro_wide(const Txt &txt, uint32_t la, uint32_t gfull, uint32_t n
         const uint32_t hit = any_wide<W>(cand);
         sa.put(m, (c4 >> (8 * ii)) & 0xFFu, hit);
         m = add_nz(m, hit);
-        shl1_le(win, i + 1u, bound);
+        shl1_le(win, wave_uniform(i + 1u), bound); // (the column index: uniform -- shl1_le takes it from a scalar register)
     };
     uint32_t g = 0;
     for (; g < gfull && g < ng4; ++g) {

@@ -127,6 +127,8 @@ def lib():
     L.strsim_ctx_last_long_rows.argtypes = [vp]
     L.strsim_column_from_views.restype = i32
     L.strsim_column_from_views.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.strsim_column_from_views_bounded.restype = i32
+    L.strsim_column_from_views_bounded.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, vp]
     L.strsim_ctx_last_late_rows.restype = u64
     L.strsim_ctx_last_late_rows.argtypes = [vp]
     L.strsim_codec_decode_gathered.restype = i32

@@ -128,16 +128,25 @@ class Context:
         check(lib().strsim_offsets_from_lengths(self._h, lengths.data_ptr(), int(n), out.data_ptr()))
         return out
 
-    def column_from_views(self, views, long_values, packed_bytes):
+    def column_from_views(self, views, long_values, packed_bytes, bounded=True):
         """Utf8View slots on the device (uint8 tensor of rows x 16 bytes; slots of strings beyond 12 bytes carry their offset in
-        `long_values` in their last word) -> (offsets int32 [rows + 1], values uint8 [packed_bytes + 64]): strsim_column_from_views."""
+        `long_values` in their last word) -> (offsets int32 [rows + 1], values uint8 [packed_bytes + 64]).  `bounded` (ABI 1.5,
+        strsim_column_from_views_bounded): the extents of both buffers are stated, a slot that reaches outside them is skipped and
+        counted -> a third result, an int32 tensor of one element (read it after synchronize()); False: strsim_column_from_views."""
         import torch
         rows = views.numel() // 16
         off = torch.empty(rows + 1, dtype=torch.int32, device=views.device)
         val = torch.zeros(int(packed_bytes) + 64, dtype=torch.uint8, device=views.device)
-        check(lib().strsim_column_from_views(self._h, views.data_ptr(), rows, long_values.data_ptr() if long_values is not None else None,
-                                             off.data_ptr(), val.data_ptr()))
-        return off, val
+        if not bounded:
+            check(lib().strsim_column_from_views(self._h, views.data_ptr(), rows, long_values.data_ptr() if long_values is not None else None,
+                                                 off.data_ptr(), val.data_ptr()))
+            return off, val
+        bad = torch.zeros(1, dtype=torch.int32, device=views.device)
+        check(lib().strsim_column_from_views_bounded(self._h, views.data_ptr(), rows,
+                                                     long_values.data_ptr() if long_values is not None else None,
+                                                     long_values.numel() if long_values is not None else 0,
+                                                     off.data_ptr(), val.data_ptr(), val.numel(), bad.data_ptr()))
+        return off, val, bad
 
     def retire_oldest(self):
         """Retire the oldest pending call only (the caller knows by an event of its own that it has completed)."""

@@ -669,6 +669,30 @@ def test_one_launch_calls_and_deferred_slow_rows(S, measure):
             assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "%s, in flight, %d slow rows" % (measure, k))
 
 
+def test_more_calls_in_flight_than_the_ring_holds(S):
+    """40 one-launch calls enqueued back to back without a single retirement -- more than the context's ring of 32 status
+    slots -- one of them with slow rows.  At the wrap the library retires what is pending inside strsim_pairs_device (documented);
+    what that finished late is carried to the caller's next retirement, and every result is the oracle's."""
+    order = [0] * 5 + [700] + [0] * 34
+    frames = {k: _mixed_frame(S, k) for k in (0, 700)}
+    exp = {k: O.batch_strings("jaro_winkler", f[0], f[1], 8) for k, f in frames.items()}
+    with S.Context(0, one_launch=True) as ctx:
+        outs = [ctx.pairs_device("jaro_winkler", *frames[k][2]) for k in order]
+        ctx.synchronize()
+        assert ctx.last_late_rows >= 700  # the sixth call's slow rows were finished at the wrap: reported with THIS retirement
+        for o, k in zip(outs, order):
+            assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "ring wrap, %d slow rows" % k)
+        # an eager small call that leaves nothing pending does not wipe what pending calls still have to report
+        small = tuple(t[:101] if i % 2 == 0 else t for i, t in enumerate(frames[0][2]))
+        ctx.pairs_device("jaro", *frames[700][2])  # (pending, one launch, slow rows inside)
+        import numpy as _np
+        A, B = frames[0][0][:100], frames[0][1][:100]
+        oa, va = S.pack_strings(A)
+        ob, vb = S.pack_strings(B)
+        got = ctx.pairs_host("jaro", oa, va, ob, vb)  # the in-place host path: strsim_pairs_device_small + synchronize
+        assert_bit_exact(got, O.batch_strings("jaro", A, B, 2), A, B, "small call beside a pending one")
+
+
 def test_pipelined_caller_with_early_copies_and_retire_oldest(S):
     """The documented pattern of a pipelined caller in one-launch mode -- own event behind each call, an EARLY device-to-host
     copy behind it, retire_oldest() in order, copy again when last_late_rows says a pass ran late -- with seven calls in flight:
@@ -919,9 +943,54 @@ def test_column_from_views(S, ctx):
         torch.cuda.synchronize()
         if n == 0:
             dv = dv[:0]
-        off, val = ctx.column_from_views(dv, dl, total)
-        ctx.synchronize()
         eo = np.zeros(n + 1, dtype=np.uint32)
         eo[1:] = np.cumsum([len(r) for r in rows], dtype=np.uint64).astype(np.uint32)
-        assert (off.cpu().numpy().view(np.uint32) == eo).all(), n
-        assert bytes(val.cpu().numpy()[:total]) == b"".join(rows), n
+        for bounded in (True, False):  # (ABI 1.5: the extents stated / the 1.4 call)
+            res = ctx.column_from_views(dv, dl, total, bounded=bounded)
+            ctx.synchronize()
+            off, val = res[0], res[1]
+            assert (off.cpu().numpy().view(np.uint32) == eo).all(), n
+            assert bytes(val.cpu().numpy()[:total]) == b"".join(rows), n
+            if bounded:
+                assert int(res[2].item()) == 0
+
+
+def test_column_from_views_malformed_slots_cannot_fault(S, ctx):
+    """a slot whose string lies outside the shipped long-string bytes, a NULL long-string buffer with long slots, a slot
+    with an absurd length (the running offset leaves 32 bits): nothing is read or written outside the stated extents -- the bad
+    rows are skipped and counted, the good rows in front of them arrive."""
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def view(length, inline=b"", at=0):
+        v = np.zeros(16, dtype=np.uint8)
+        v[:4] = np.frombuffer(np.uint32(length).tobytes(), dtype=np.uint8)
+        if length <= 12:
+            v[4:4 + len(inline)] = np.frombuffer(inline, dtype=np.uint8)
+        else:
+            v[12:16] = np.frombuffer(np.uint32(at).tobytes(), dtype=np.uint8)
+        return v
+
+    longs = torch.from_numpy(np.frombuffer(b"0123456789abcdefghijklmnopqrstuvwxyz", dtype=np.uint8).copy()).to(dev)
+    good = [view(3, b"abc"), view(20, at=4), view(0)]
+    # (1) an offset far outside the 36 shipped bytes; (2) a string that starts inside and ends outside
+    for bad_view in (view(20, at=1 << 30), view(30, at=20)):
+        vs = np.concatenate(good + [bad_view, view(2, b"zz")])
+        off, val, bad = ctx.column_from_views(torch.from_numpy(vs).to(dev), longs, 3 + 20 + 0 + 30 + 2)
+        ctx.synchronize()
+        assert int(bad.item()) == 1
+        assert bytes(val.cpu().numpy()[:23]) == b"abc" + b"456789abcdefghijklmn"
+    # (3) long slots but no long-string buffer at all (both forms of the call)
+    vs = np.concatenate(good)
+    off, val, bad = ctx.column_from_views(torch.from_numpy(vs).to(dev), None, 23)
+    ctx.synchronize()
+    assert int(bad.item()) == 1 and bytes(val.cpu().numpy()[:3]) == b"abc"
+    off, val = ctx.column_from_views(torch.from_numpy(vs).to(dev), None, 23, bounded=False)
+    ctx.synchronize()
+    assert bytes(val.cpu().numpy()[:3]) == b"abc"
+    # (4) absurd lengths: three slots of 2^31 bytes push the running offset past 2^32 -- every row behind them is out of range
+    vs = np.concatenate([view(3, b"abc")] + [view(1 << 31, at=0)] * 3 + [view(2, b"zz")] * 3000)
+    off, val, bad = ctx.column_from_views(torch.from_numpy(vs).to(dev), longs, 4096)
+    ctx.synchronize()
+    assert int(bad.item()) == 3 + 3000 and bytes(val.cpu().numpy()[:3]) == b"abc"
+    assert not val.cpu().numpy()[3:].any()  # nothing else was written
