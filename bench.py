@@ -50,6 +50,10 @@ def parse():
     p.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     p.add_argument("--cpu-sample-rows", type=int, default=0)
     p.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive plugin-ABI measurement (N=1 extra field)")
+    p.add_argument("--root-share", type=float, default=1.0,
+                   help="N>1, strong scaling: rank 0 takes this fraction of an equal share and the other ranks split the rest "
+                        "(rank 0 also decodes the gathered column: profiles/r5_root_rehearsal.txt).  A DEVIATION from the reference's "
+                        "partition (split_offsets, strsim.rs:21-39), off by default (1.0) and named in the JSON line when used")
     return p.parse_args()
 
 
@@ -207,6 +211,12 @@ def main():
     else:
         total_rows = a.rows or cfg[1]
         shards = S.split_offsets(total_rows, world)  # strsim.rs:21-39
+        if world > 1 and a.root_share != 1.0:
+            if not 0.0 <= a.root_share <= 1.0:
+                raise SystemExit("--root-share is a fraction of an equal share: 0 .. 1")
+            r0 = int(total_rows // world * a.root_share) // 64 * 64
+            rest = S.split_offsets(total_rows - r0, world - 1)  # the reference's rule over the remaining ranks
+            shards = [(0, r0)] + [(r0 + o, ln) for o, ln in rest]
     row_base, rows = shards[rank]
 
     # a shard whose packed values would not fit 32-bit offsets (cfg5: ~5 GB per column) is held as several row batches,
@@ -430,6 +440,8 @@ def main():
                        # the default stream-ordered mode (every kernel of the chain up front) under the gather
                        "call_mode": "stream_ordered (ABI default)" if gather else "one_launch (opt-in, strsim_ctx_set_stream_ordered(ctx, 0))",
                        "calls_in_flight_max": None if gather else INFLIGHT * calls_per_step,
+                       "partition": "split_offsets(rows, N) (strsim.rs:21-39)" if (world == 1 or a.root_share == 1.0 or a.scaling == "weak")
+                                    else "DEVIATION --root-share %g: rank 0 holds %d rows, the others split the rest by split_offsets" % (a.root_share, rows),
                        "distributed": distributed,
                        "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded */
+#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded, strsim_codec_decode_gathered_from, STRSIM_ERR_EARLIER_CALL */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -298,6 +298,12 @@ STRSIM_API int strsim_codec_patch_indirect(strsim_ctx_t *ctx, double *out, uint6
 STRSIM_API int strsim_codec_decode_gathered(strsim_ctx_t *ctx, const strsim_codec_t *codec, const void *buf, uint64_t seg_stride_bytes,
                                             uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed, uint64_t code_bytes,
                                             uint32_t exc_cap, double *out, uint32_t *overflow);
+/* The same over segments first_seg .. nseg - 1 only (ABI 1.5): the root of a gather has no reason to code and decode its OWN shard --
+ * it copies its f64 results into `out` and decodes the peers' segments (first_seg = 1: an eighth of the decode and the whole
+ * encode off the rank that every step waits for, profiles/r5_root_rehearsal.txt).  Row r * chunk_rows is still segment r's first. */
+STRSIM_API int strsim_codec_decode_gathered_from(strsim_ctx_t *ctx, const strsim_codec_t *codec, const void *buf, uint64_t seg_stride_bytes,
+                                                 uint32_t first_seg, uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed,
+                                                 uint64_t code_bytes, uint32_t exc_cap, double *out, uint32_t *overflow);
 
 #define STRSIM_LANE_PATH_MAX_BYTES 32u   /* lane-per-pair kernels: both strings <= 32 bytes, ASCII */
 #define STRSIM_WAVE_PATH_MAX_BYTES 1024u /* wave-per-pair kernels: both strings <= 1024 bytes, any UTF-8 */

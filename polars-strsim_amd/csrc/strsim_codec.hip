@@ -177,17 +177,46 @@ __global__ void k_encode_packed(const double *__restrict__ vals, uint64_t n, uns
     }
 }
 
-// one row per thread (coalesced stores; the `per` threads of a word share its load): row i sits in word i / per at
-// bit (i % per) * bits; `magic` = ceil(2^64 / per), exact for i < 2^32
-__global__ void k_decode_packed(const unsigned long long *__restrict__ words, uint64_t n, uint32_t per, uint32_t bits,
-                                unsigned long long magic, double *__restrict__ out, const double *__restrict__ table)
+// Packed codes -> f64, one row per thread and trip (coalesced 8-byte stores; the `per` threads of a word share its load): row i
+// sits in word i / per at bit (i % per) * bits.  [r5] Rows are walked in TILES of 256 whole words (per x 256 rows) so that the
+// division is of a number below 8 192 by a launch constant -- one v_mul_hi_u32 with magic32 = ceil(2^32 / per), exact for
+// x * (per - 1) < 2^32 -- where rounds 3-4 divided the 64-bit row index (a 64 x 64 -> 128-bit multiply per row: the root's decode
+// of a gathered cfg2 column ran at 2.9 x its byte roofline, profiles/r5_root_rehearsal.txt); and a table of up to
+// DECODE_LDS_ENTRIES values (Levenshtein: 325, Jaccard / Dice: 631) is read from LDS instead of through the address unit.
+// Escaped rows are left untouched (patched from the exception list).
+constexpr uint32_t DECODE_LDS_ENTRIES = 2048;
+template <bool LDS_TABLE>
+__device__ __forceinline__ void decode_tiles(const unsigned long long *__restrict__ words, uint64_t n, uint32_t per, uint32_t bits,
+                                             uint32_t magic32, double *__restrict__ out, const double *__restrict__ table,
+                                             const double *s_tab, uint64_t tile0, uint64_t tile_step)
 {
     const unsigned long long esc = (1ull << bits) - 1ull;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t w = __umul64hi(i, magic);
-        const uint32_t j = (uint32_t)(i - w * per);
-        const unsigned long long code = (words[w] >> (j * bits)) & esc;
-        if (code != esc) out[i] = table[code]; // escaped rows are left untouched (patched from the exception list)
+    const uint32_t tile_rows = per * 256u, tid = threadIdx.x;
+    const uint64_t ntiles = (n + tile_rows - 1u) / tile_rows;
+    for (uint64_t tile = tile0; tile < ntiles; tile += tile_step) {
+        const uint64_t row0 = tile * tile_rows;
+        const unsigned long long *__restrict__ const wt = words + tile * 256u;
+        const uint32_t left = (uint32_t)(n - row0 < (uint64_t)tile_rows ? n - row0 : (uint64_t)tile_rows);
+        for (uint32_t x = tid; x < left; x += 256u) {
+            const uint32_t wl = __umulhi(x, magic32); // x / per
+            const uint32_t k = x - wl * per;
+            const uint32_t code = (uint32_t)((wt[wl] >> (k * bits)) & esc);
+            if (code != (uint32_t)esc) out[row0 + x] = LDS_TABLE ? s_tab[code] : table[code];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_decode_packed(const unsigned long long *__restrict__ words, uint64_t n, uint32_t per, uint32_t bits,
+                                                       uint32_t magic32, double *__restrict__ out, const double *__restrict__ table,
+                                                       uint32_t entries)
+{
+    __shared__ double s_tab[DECODE_LDS_ENTRIES];
+    if (entries <= DECODE_LDS_ENTRIES) {
+        for (uint32_t i = threadIdx.x; i < entries; i += 256u) s_tab[i] = table[i];
+        __syncthreads();
+        decode_tiles<true>(words, n, per, bits, magic32, out, table, s_tab, blockIdx.x, gridDim.x);
+    } else {
+        decode_tiles<false>(words, n, per, bits, magic32, out, table, s_tab, blockIdx.x, gridDim.x);
     }
 }
 
@@ -215,22 +244,24 @@ __global__ void k_patch_indirect(double *__restrict__ out, uint64_t row_base, co
 // code) or 16-bit -- and, code_bytes into the segment, its exception block (count | rows | values, cap entries); rows
 // r * chunk .. of `out` are decoded and the exceptions written over the rows the codes escaped (disjoint rows: no order between
 // the two is needed).  Replaces one decode + one patch launch per peer and column.
-__global__ void k_decode_gathered(const uint8_t *__restrict__ buf, uint64_t stride, uint32_t nseg, uint64_t chunk, uint64_t last_rows,
-                                  uint32_t packed, uint32_t per, uint32_t bits, unsigned long long magic, uint64_t code_bytes,
-                                  uint32_t cap, double *__restrict__ out, const double *__restrict__ table, uint32_t *__restrict__ overflow)
+__global__ __launch_bounds__(256) void k_decode_gathered(const uint8_t *__restrict__ buf, uint64_t stride, uint32_t nseg, uint64_t chunk, uint64_t last_rows,
+                                  uint32_t packed, uint32_t per, uint32_t bits, uint32_t magic32, uint64_t code_bytes,
+                                  uint32_t cap, double *__restrict__ out, const double *__restrict__ table, uint32_t entries,
+                                  uint32_t *__restrict__ overflow, uint32_t seg0)
 {
-    const uint32_t seg = blockIdx.y;
+    __shared__ double s_tab[DECODE_LDS_ENTRIES];
+    const uint32_t seg = seg0 + blockIdx.y; // (seg0: the root's own segment is not coded at all -- strsim_codec_decode_gathered_from)
     const uint8_t *base = buf + (uint64_t)seg * stride;
     const uint64_t n = seg + 1u == nseg ? last_rows : chunk;
     double *o = out + (uint64_t)seg * chunk;
     if (packed) {
         const unsigned long long *words = reinterpret_cast<const unsigned long long *>(base);
-        const unsigned long long esc = (1ull << bits) - 1ull;
-        for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-            const uint64_t w = __umul64hi(i, magic);
-            const uint32_t j = (uint32_t)(i - w * per);
-            const unsigned long long code = (words[w] >> (j * bits)) & esc;
-            if (code != esc) o[i] = table[code];
+        if (entries <= DECODE_LDS_ENTRIES) { // (uniform over the launch)
+            for (uint32_t i = threadIdx.x; i < entries; i += 256u) s_tab[i] = table[i];
+            __syncthreads();
+            decode_tiles<true>(words, n, per, bits, magic32, o, table, s_tab, blockIdx.x, gridDim.x);
+        } else {
+            decode_tiles<false>(words, n, per, bits, magic32, o, table, s_tab, blockIdx.x, gridDim.x);
         }
     } else {
         const uint16_t *codes = reinterpret_cast<const uint16_t *>(base);
@@ -640,6 +671,18 @@ int strsim_codec_decode_gathered(strsim_ctx_t *ctx, const strsim_codec_t *c, con
                                  uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed, uint64_t code_bytes,
                                  uint32_t exc_cap, double *out, uint32_t *overflow)
 {
+    return strsim_codec_decode_gathered_from(ctx, c, buf, seg_stride_bytes, 0u, nseg, chunk_rows, last_rows, packed, code_bytes, exc_cap, out, overflow);
+}
+
+int strsim_codec_decode_gathered_from(strsim_ctx_t *ctx, const strsim_codec_t *c, const void *buf, uint64_t seg_stride_bytes,
+                                      uint32_t first_seg, uint32_t nseg, uint64_t chunk_rows, uint64_t last_rows, int packed,
+                                      uint64_t code_bytes, uint32_t exc_cap, double *out, uint32_t *overflow)
+{
+    if (first_seg >= nseg) {
+        if (first_seg == nseg && ctx && c && buf && out && overflow) return STRSIM_OK; // nothing to decode
+        set_error("strsim_codec_decode_gathered: first_seg beyond the segments");
+        return STRSIM_ERR_ARG;
+    }
     if (!ctx || !c || !buf || !out || !overflow || nseg == 0) { set_error("strsim_codec_decode_gathered: NULL argument"); return STRSIM_ERR_ARG; }
     if ((reinterpret_cast<uintptr_t>(buf) & 7u) || (seg_stride_bytes & 7u) || (code_bytes & 15u)) {
         set_error("strsim_codec_decode_gathered: the buffer and the segment stride must be 8-byte, code_bytes 16-byte aligned");
@@ -648,11 +691,14 @@ int strsim_codec_decode_gathered(strsim_ctx_t *ctx, const strsim_codec_t *c, con
     if (nseg > 65535u || (chunk_rows >> 32) || (last_rows >> 32)) { set_error("strsim_codec_decode_gathered: too many segments / rows"); return STRSIM_ERR_ARG; }
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
     const uint32_t bits = strsim_codec_bits(c), per = 64u / bits;
-    const unsigned long long magic = ~0ull / per + 1ull;
+    const uint32_t magic32 = (uint32_t)(((1ull << 32) + per - 1u) / per); // ceil(2^32 / per): x / per for x < 2^32 / per
     const uint64_t mx = std::max<uint64_t>(chunk_rows, last_rows);
-    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((mx + 255) / 256, 1), 4096);
-    hipLaunchKernelGGL(k_decode_gathered, dim3(gx, nseg), dim3(256), 0, st, static_cast<const uint8_t *>(buf), seg_stride_bytes, nseg,
-                       chunk_rows, last_rows, packed ? 1u : 0u, per, bits, magic, code_bytes, exc_cap, out, c->d_table, overflow);
+    // workgroups per segment: one per tile of per x 256 rows (packed) / 256 rows, at most 8 192 / segments -- a few per CU and segment
+    const uint64_t units = packed ? (mx + per * 256ull - 1) / (per * 256ull) : (mx + 255) / 256;
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(units, 1), std::max<uint64_t>(8192 / nseg, 256));
+    hipLaunchKernelGGL(k_decode_gathered, dim3(gx, nseg - first_seg), dim3(256), 0, st, static_cast<const uint8_t *>(buf), seg_stride_bytes, nseg,
+                       chunk_rows, last_rows, packed ? 1u : 0u, per, bits, magic32, code_bytes, exc_cap, out, c->d_table, c->entries, overflow,
+                       first_seg);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }
@@ -695,9 +741,10 @@ int strsim_codec_decode_packed(strsim_ctx_t *ctx, const strsim_codec_t *c, const
     if (reinterpret_cast<uintptr_t>(words) & 7u) { set_error("strsim_codec_decode_packed: words must be 8-byte aligned"); return STRSIM_ERR_ARG; }
     hipStream_t st = (hipStream_t)strsim_ctx_stream(ctx);
     const uint32_t bits = strsim_codec_bits(c), per = 64u / bits;
-    const unsigned long long magic = ~0ull / per + 1ull; // ceil(2^64 / per) for per that is not a power of two, exact else too
-    hipLaunchKernelGGL(k_decode_packed, dim3(grid_for(n)), dim3(256), 0, st,
-                       reinterpret_cast<const unsigned long long *>(words), n, per, bits, magic, out, c->d_table);
+    const uint32_t magic32 = (uint32_t)(((1ull << 32) + per - 1u) / per); // ceil(2^32 / per)
+    const uint64_t tiles = (n + per * 256ull - 1) / (per * 256ull);
+    hipLaunchKernelGGL(k_decode_packed, dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 8192)), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned long long *>(words), n, per, bits, magic32, out, c->d_table, c->entries);
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }

@@ -133,6 +133,8 @@ def lib():
     L.strsim_ctx_last_late_rows.argtypes = [vp]
     L.strsim_codec_decode_gathered.restype = i32
     L.strsim_codec_decode_gathered.argtypes = [vp, vp, vp, u64, C.c_uint32, u64, u64, i32, u64, C.c_uint32, vp, vp]
+    L.strsim_codec_decode_gathered_from.restype = i32
+    L.strsim_codec_decode_gathered_from.argtypes = [vp, vp, vp, u64, C.c_uint32, C.c_uint32, u64, u64, i32, u64, C.c_uint32, vp, vp]
     L.strsim_compact_segments.restype = i32
     L.strsim_compact_segments.argtypes = [vp, vp, vp, vp, vp, vp, i32]
     L.strsim_ctx_enqueued_ops.restype = u64

@@ -275,13 +275,15 @@ class Codec:
         check(lib().strsim_codec_patch_indirect(ctx._h, out.data_ptr(), int(row_base), cnt.data_ptr(), rows.data_ptr(),
                                                 vals.data_ptr(), min(rows.numel(), vals.numel()), overflow.data_ptr()))
 
-    def decode_gathered(self, buf, seg_stride_bytes, nseg, chunk_rows, last_rows, packed, code_bytes, exc_cap, out, overflow, ctx=None):
+    def decode_gathered(self, buf, seg_stride_bytes, nseg, chunk_rows, last_rows, packed, code_bytes, exc_cap, out, overflow, ctx=None,
+                        first_seg=0):
         """The root's decode of every rank's segment of a gathered buffer (codes + exception block each) in ONE launch:
-        strsim_codec_decode_gathered."""
+        strsim_codec_decode_gathered; `first_seg` = 1 leaves the root's own segment alone (strsim_codec_decode_gathered_from: the
+        root copies its f64 shard in instead of coding and decoding it)."""
         ctx = ctx or self.ctx
-        check(lib().strsim_codec_decode_gathered(ctx._h, self._h, buf.data_ptr(), int(seg_stride_bytes), int(nseg), int(chunk_rows),
-                                                 int(last_rows), 1 if packed else 0, int(code_bytes), int(exc_cap), out.data_ptr(),
-                                                 overflow.data_ptr()))
+        check(lib().strsim_codec_decode_gathered_from(ctx._h, self._h, buf.data_ptr(), int(seg_stride_bytes), int(first_seg), int(nseg),
+                                                      int(chunk_rows), int(last_rows), 1 if packed else 0, int(code_bytes), int(exc_cap),
+                                                      out.data_ptr(), overflow.data_ptr()))
 
     def patch(self, out, row_base, exc_rows, exc_vals, count, ctx=None):
         ctx = ctx or self.ctx

@@ -68,7 +68,7 @@ class ShardGatherer:
     """
 
     def __init__(self, ctx, compute_stream, measures, rows, device, backend="nccl", codec_chars=None, parts=None,
-                 exc_ship=65536):
+                 exc_ship=65536, root_plain=True):
         """`compute_stream`: the torch stream whose handle `ctx` was created with (the kernels' stream).
         `rows`: this rank's shard length when `parts` is None (every rank the same), else ignored."""
         import strsim_amd as S
@@ -95,6 +95,7 @@ class ShardGatherer:
         self.ctx_comm = S.Context(ctx.device, stream=self.comm.cuda_stream)
         self.ctx_decode = S.Context(ctx.device, stream=self.decode.cuda_stream)
         self.nsub = 0
+        self.root_plain = bool(root_plain)  # the root's own shard goes into the gathered column as it is (no encode / decode)
         self.timing = False      # timing_begin(): event pairs around every shipment (encode + gather) and every root decode
         self._t_ship, self._t_dec = [], []
         self.codecs = {}
@@ -162,8 +163,14 @@ class ShardGatherer:
                 if buf is None:
                     buf = self.codes[slot] = torch.zeros(self.ship_bytes, dtype=torch.uint8, device=self.dev)
                 exc = self._exc_views(buf, self.code_bytes)
-                # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's kernels
-                if self.packed:
+                # encode on the side stream too: it is a memory/latency-bound pass that overlaps the next step's kernels.
+                # [r5] The ROOT does not code its own shard: it copies the f64 results into the gathered column (one device copy) and
+                # ships a segment nobody reads -- every step waits for the root, which also decodes the peers' segments
+                # (bench_support/bench_root_rehearsal.py: encode 0.09 ms + an eighth of the decode per step at N = 8).
+                if self.rank == 0 and self.root_plain:
+                    off0, ln0 = self.parts[0]
+                    self.recv[off0:off0 + ln0].copy_(out, non_blocking=True)
+                elif self.packed:
                     codec.encode_packed(out, buf[:self.code_bytes].view(torch.int64), ctx=self.ctx_comm, exc=exc)
                 else:
                     codec.encode(out, buf[:2 * self.rows].view(torch.int16), ctx=self.ctx_comm, exc=exc)
@@ -187,9 +194,12 @@ class ShardGatherer:
                             # every rank coded its own shard; the shards are split_offsets' (equal, the last one longer): ONE launch
                             # decodes all segments and writes their exception blocks in
                             codec.decode_gathered(rc, self.ship_bytes, self.world, chunk, self.parts[-1][1], self.packed, self.code_bytes,
-                                                  self.exc_ship, self.recv, self.overflow, ctx=self.ctx_decode)
+                                                  self.exc_ship, self.recv, self.overflow, ctx=self.ctx_decode,
+                                                  first_seg=1 if self.root_plain else 0)
                         else:
                             for r, (off, ln) in enumerate(self.parts):  # any other partition: segment by segment
+                                if r == 0 and self.root_plain:
+                                    continue
                                 seg = rc[r * self.ship_bytes:(r + 1) * self.ship_bytes]
                                 dst = self.recv[off:off + ln]
                                 if self.packed:
@@ -253,8 +263,13 @@ class ShardGatherer:
         return (sum(ship) / len(ship) if ship else None), (sum(dec) / len(dec) if dec else None)
 
     def exceptions(self):
-        """Rows outside the codec's table in the LAST shard this rank coded (they travelled in the exception block)."""
+        """Rows outside the codec's table in the LAST shard coded (they travelled in the exception block): this rank's own, and on
+        the root -- whose own shard is not coded when root_plain -- the largest count among the segments it received last."""
         n = 0
         for buf in self.codes.values():
             n = max(n, int(self._exc_views(buf, self.code_bytes)[0].item()))
+        if self.rank == 0 and self.recv_codes is not None and self.nsub:
+            rc = self.recv_codes[(self.nsub - 1) & 1]
+            for r in range(1 if self.root_plain else 0, self.world):
+                n = max(n, int(self._exc_views(rc, r * self.ship_bytes + self.code_bytes)[0].item()))
         return n

@@ -84,6 +84,16 @@ def test_ragged_shards(extra):
     assert d["config"]["rows_rank0"] == 500000 and d["config"]["gather_verified"] is True
 
 
+def test_root_share_is_a_named_deviation():
+    """--root-share 0.5: rank 0 (which also decodes the gathered column) holds half an equal share; the line says so, and what rank 0
+    gathered still equals every rank's shard (an uneven partition: the segments are decoded one by one)."""
+    d = _run(["--root-share", "0.5"], rows="1000000")
+    assert d["config"]["rows_rank0"] == 249984 and d["config"]["partition"].startswith("DEVIATION")  # (whole 64-row chunks)
+    assert d["config"]["gather_verified"] is True
+    d = _run([], rows="1000000")
+    assert d["config"]["partition"].startswith("split_offsets")
+
+
 def test_weak_scaling_option():
     d = _run(["--scaling", "weak"], rows="300000")
     assert d["scaling"] == "weak" and d["config"]["rows_total"] == 600000 and d["config"]["gather_verified"] is True
