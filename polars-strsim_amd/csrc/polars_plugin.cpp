@@ -779,11 +779,7 @@ uint64_t direct_rows() // read per call: a test (or a user) can switch the path 
     const char *e = getenv("POLARS_STRSIM_DIRECT_ROWS");
     return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)131072;
 }
-uint64_t direct_bytes()
-{
-    const char *e = getenv("POLARS_STRSIM_DIRECT_BYTES");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)2 << 20;
-}
+uint64_t direct_bytes() { return (uint64_t)2 << 20; }
 
 void *mapped(void *pinned)
 {

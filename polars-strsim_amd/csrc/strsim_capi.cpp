@@ -531,7 +531,6 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
         c->enqueued_ops += (uint64_t)lane_kernel_launches(measure, la);
         HIP_TRY(hipStreamSynchronize(c->stream));
         const uint32_t left = *reinterpret_cast<volatile uint32_t *>(&c->status_host[slot].lane_left);
-        if (getenv("STRSIM_TRACE")) fprintf(stderr, "[strsim] eager call: %llu rows, %u left behind the lane kernel\n", (unsigned long long)n, left);
         if (left == 0u) {
             // nothing pending FOR THIS CALL: strsim_ctx_synchronize() has nothing to retire for it.  The last_* counters describe
             // the last retirement; they are only reset when no other call of this context is still pending (a caller

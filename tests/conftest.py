@@ -27,7 +27,7 @@ def _have_gpu():
 # the minutes-long full-size / fuzz files last -- whatever the alphabet says.
 _FILE_ORDER = ["test_abi_symbols.py", "test_plugin_abi_gpu.py", "test_plugin_configs_gpu.py", "test_hip_runtime_sharing.py",
                "test_gpu_parity.py", "test_gpu_multirank_smoke.py", "test_packaging.py", "test_installed_wheel_gpu.py"]
-_FILE_LAST = ["test_gpu_hypothesis.py", "test_gpu_fuzz.py", "test_gpu_fullsize.py"]
+_FILE_LAST = ["test_knobs_gpu.py", "test_gpu_hypothesis.py", "test_gpu_fuzz.py", "test_gpu_fullsize.py"]
 
 
 def _file_rank(item):

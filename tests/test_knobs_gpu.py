@@ -1,0 +1,69 @@
+"""Every environment knob the library reads (grep getenv polars-strsim_amd/csrc), at a non-default value, through the plugin ABI
+on a mixed 100 000-row frame in both engine modes, against the oracle -- VERDICT r4 item 4: a documented knob that no parity test
+has ever run is a product branch nobody has seen work.  Most knobs are read once per process, so each case is a fresh interpreter
+(tests/helpers/knob_child.py)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "helpers", "knob_child.py")
+
+KNOBS = [
+    {},  # the defaults, for reference
+    {"POLARS_STRSIM_ONE_PASS": "0"},
+    {"POLARS_STRSIM_PARALLEL_PACK": "0"},
+    {"POLARS_STRSIM_STREAM_STORES": "0"},
+    {"POLARS_STRSIM_STREAM_STORES": "1"},
+    {"POLARS_STRSIM_PACK_THREADS": "1"},
+    {"POLARS_STRSIM_PACK_THREADS": "3"},
+    {"POLARS_STRSIM_LENGTH_BYTES": "0"},
+    {"POLARS_STRSIM_PINNED_OUT": "0"},
+    {"POLARS_STRSIM_DIRECT_ROWS": "0"},
+    {"POLARS_STRSIM_DIRECT_ROWS": "1000000"},
+    {"POLARS_STRSIM_VIEWS": "1"},
+    {"POLARS_STRSIM_TRACE": "1"},
+    {"POLARS_STRSIM_DEVICE": "0"},
+    {"POLARS_STRSIM_DEVICES": "0,0", "POLARS_STRSIM_MIN_ROWS_PER_DEVICE": "20000"},
+    {"POLARS_STRSIM_SINGLE_SLICE_ROWS": "1000", "POLARS_STRSIM_RAMP_ROWS": "8192", "POLARS_STRSIM_RAMP_GROW_PCT": "110", "POLARS_STRSIM_SLICE_ROWS": "30000"},
+    {"POLARS_STRSIM_SINGLE_SLICE_ROWS": "1000", "POLARS_STRSIM_RAMP_ROWS": "70000", "POLARS_STRSIM_RAMP_GROW_PCT": "400"},
+    {"STRSIM_NO_LITERAL_PATH": "1"},
+    {"STRSIM_HOST_DIRECT_ROWS": "0"},
+    {"STRSIM_STAGE_WG_PER_CU": "1"},
+    {"STRSIM_STAGE_WG_PER_CU": "8"},
+    {"STRSIM_WIDE_WG_PER_CU": "1"},
+    {"STRSIM_WIDE_WG_PER_CU": "1000"},
+    {"STRSIM_LEV_WAVES_PER_CU": "1"},
+    {"STRSIM_LEV_WAVES_PER_CU": "64"},
+    {"STRSIM_HUGE_WAVES_PER_CU": "1"},
+    {"STRSIM_HUGE_WAVES_PER_CU": "32"},
+]
+
+
+def knob_names_in_source():
+    names = set()
+    src = os.path.join(ROOT, "polars-strsim_amd", "csrc")
+    for f in os.listdir(src):
+        if os.path.isfile(os.path.join(src, f)):
+            names |= set(re.findall(r'(?:getenv|env_rows)\("([A-Z_0-9]+)"', open(os.path.join(src, f)).read()))
+    return names
+
+
+def test_every_knob_the_source_reads_is_in_this_file():
+    """(no GPU needed) grep getenv csrc/ lists no name that this test does not run."""
+    tested = set().union(*[set(k) for k in KNOBS])
+    assert knob_names_in_source() <= tested, sorted(knob_names_in_source() - tested)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()) or "defaults")
+def test_knob_at_a_non_default_value_matches_the_oracle(knobs):
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("POLARS_STRSIM_") or k.startswith("STRSIM_"))}
+    env.update(knobs)
+    r = subprocess.run([sys.executable, CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "KNOBS-OK" in r.stdout, (knobs, r.stdout[-500:], r.stderr[-3000:])
+    if "POLARS_STRSIM_TRACE" in knobs:
+        assert "pack" in r.stderr  # (the per-call phase times went to stderr)
