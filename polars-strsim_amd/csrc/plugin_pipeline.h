@@ -1,0 +1,356 @@
+// plugin_pipeline.h -- one call's rows through the device pipelines (slices packed, shipped, computed and fetched while the next one is packed;
+// literals; small calls in place), and the output validity built word-wise on the packing pool.
+// Included by polars_plugin.cpp inside its anonymous namespace, in this order ([r5] split out of polars_plugin.cpp along its seams,
+// no behaviour change -- the object code is identical before and after).
+// Reference: parallel_apply, /root/reference/src/expressions/strsim.rs:41-107.
+#pragma once
+
+struct PhaseTimer { // POLARS_STRSIM_TRACE=1: per-phase wall times of one plugin call on stderr
+    bool on;
+    double t_pack = 0, t_copy = 0;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(getenv("POLARS_STRSIM_TRACE") != nullptr) {}
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void stop(double &acc) { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// a row-count tuning knob from the environment (unset, empty or 0: the default)
+uint64_t env_rows(const char *name, uint64_t dflt)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const unsigned long long v = strtoull(e, nullptr, 10);
+    return v ? (uint64_t)v : dflt;
+}
+
+struct PipeTimes { double t_launch = 0, t_wait = 0, t_d2h = 0; unsigned slices = 0; };
+
+// Rows [0, n) of a call through the pipelines of `devs`: slices are packed one after the other by the calling thread's packing
+// pool -- ALL of its threads on every slice -- and dealt out to the pipelines in turn: slice i goes to pipeline i % D, into
+// slot (i / D) % 3 of it, is launched there (H2D + kernels on the pipeline's stream, the D2H of its results on the
+// pipeline's copy stream, over that device's own PCIe link) and is finished two rounds later, when slice i + 2 D has been
+// launched: two slices in flight per device while the host packs the next.  Results go straight into out[] -- by the copy
+// engine itself when the output column is pinned memory (out_pinned), else through the slot's pinned result buffer and a
+// host copy.  (Reference: the row fan-out of strsim.rs:72-100; here the host has ONE packer, so the devices take turns
+// instead of shards -- a device's share of the packing threads would be a fraction of them.)
+void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_t n, double *out, bool out_pinned, unsigned T,
+              bool direct_call, bool engine_parallel, const std::vector<int> &devs, PhaseTimer &tm, std::vector<PipeTimes> &ptimes)
+{
+    const size_t D = devs.size();
+    ptimes.assign(D, PipeTimes{});
+    std::vector<Pipe *> pipes(D);
+    std::vector<hipStream_t> streams(D);
+    for (size_t d = 0; d < D; ++d) {
+        pipes[d] = &g_pipes.at(d);
+        streams[d] = static_cast<hipStream_t>(strsim_ctx_stream(pipes[d]->open(devs[d])));
+    }
+
+    // a literal side is packed once and shipped to every pipeline
+    std::vector<const uint32_t *> lit_off_d(D, nullptr);
+    std::vector<const uint8_t *> lit_val_d(D, nullptr);
+    for (int s = 0; s < 2; ++s) {
+        if (!lit[s]) continue;
+        for (size_t d = 0; d < D; ++d) {
+            Pipe &P = *pipes[d];
+            HIP_OR_FAIL(hipSetDevice(P.device));
+            Buf &ho = P.lit_h_off, &hv = P.lit_h_val; // persistent pinned staging: the call is synchronous,
+            const uint64_t bytes = pack_slice(col[s], 0, 1, ho, hv, 1); // so no earlier copy can still be reading them
+            if (bytes > SLICE_BYTES) fail("a single string exceeds the 4 GiB limit");
+            if (direct_call && bytes <= direct_bytes()) { // small call: read in place (see direct_rows)
+                lit_off_d[d] = static_cast<const uint32_t *>(mapped(ho.p));
+                lit_val_d[d] = static_cast<const uint8_t *>(mapped(hv.p));
+                continue;
+            }
+            P.lit_off.reserve(2 * sizeof(uint32_t));
+            P.lit_val.reserve(bytes + 64);
+            HIP_OR_FAIL(hipMemcpyAsync(P.lit_off.p, ho.p, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, streams[d]));
+            if (bytes) HIP_OR_FAIL(hipMemcpyAsync(P.lit_val.p, hv.p, bytes, hipMemcpyHostToDevice, streams[d]));
+            lit_off_d[d] = static_cast<const uint32_t *>(P.lit_off.p);
+            lit_val_d[d] = static_cast<const uint8_t *>(P.lit_val.p);
+        }
+    }
+
+    // (slices computed in place read their offsets from the pinned staging; POLARS_STRSIM_LENGTH_BYTES=0: always ship offsets)
+    const char *lens8_env = getenv("POLARS_STRSIM_LENGTH_BYTES");
+    const bool lens8_ok = !(lens8_env && atoi(lens8_env) == 0) && !direct_call;
+    // bytes per row (x 256) of the call's last slice, per column: 0 = not known yet (the first slice is packed the two-pass way)
+    uint64_t bpr256[2] = {0, 0};
+    const char *onepass_env = getenv("POLARS_STRSIM_ONE_PASS");
+    const bool onepass_ok = lens8_ok && !lit[0] && !lit[1] && col[0].layout == L_VIEW && col[1].layout == L_VIEW &&
+                            !(onepass_env && atoi(onepass_env) == 0);
+    // View-native slices: two view columns, not a small call; POLARS_STRSIM_VIEWS=1 switches them on.  OFF by
+    // default, by their own measurement (profiles/r4_f1_views.txt, 10 M rows, same box): a view is 16 bytes whatever the string --
+    // more than the packed form of a short string (cfg1: 9 bytes a row and column) -- so the streaming copy writes MORE than the
+    // gather it replaces and the link carries more: 9.3 vs 5.8 ms (cfg1) and 13.6 vs 8.6 ms (cfg2) with the packing pool, 61 vs 48
+    // and 101 vs 67 ms on the calling thread alone (the engine-parallel mode), with and without non-temporal stores.
+    (void)engine_parallel;
+    const char *views_env = getenv("POLARS_STRSIM_VIEWS");
+    const bool views_ok = !direct_call && !lit[0] && !lit[1] && col[0].layout == L_VIEW && col[1].layout == L_VIEW &&
+                          views_env && atoi(views_env) != 0;
+    uint64_t lbpr256[2] = {~0ull, ~0ull}; // long bytes per row (x 256) of the call's last slice: not known yet
+    auto pack = [&](Slot &sl, uint64_t r0, uint64_t want) -> uint64_t {
+        uint64_t rows = std::min<uint64_t>(want, n - r0);
+        for (;;) {
+            bool fits = true;
+            sl.lens8[0] = sl.lens8[1] = false;
+            sl.nseg[0] = sl.nseg[1] = 0;
+            sl.as_views[0] = sl.as_views[1] = false;
+            if (views_ok) {
+                fits = pack_slice_views(col, r0, r0 + rows, sl, lbpr256, T);
+            } else if (onepass_ok && bpr256[0] && bpr256[1] && pack_slice_onepass(col, r0, r0 + rows, sl, bpr256, T)) {
+                // (one pass: lengths + values in per-thread segments)
+            } else if (!lit[0] && !lit[1]) {
+                fits = pack_slice2(col, r0, r0 + rows, sl, lens8_ok, T);
+                for (int s = 0; s < 2 && fits; ++s) bpr256[s] = sl.lens8[s] && rows ? (sl.bytes[s] * 256 + rows - 1) / rows + 1 : 0;
+            } else {
+                for (int s = 0; s < 2 && fits; ++s) {
+                    if (lit[s]) continue;
+                    sl.bytes[s] = pack_slice(col[s], r0, r0 + rows, sl.h_off[s], sl.h_val[s], T);
+                    fits = sl.bytes[s] <= SLICE_BYTES;
+                }
+            }
+            if (fits) break;
+            if (rows == 1) fail("a single string exceeds the 4 GiB limit");
+            rows = (rows + 1) / 2; // very long strings: halve the slice until its packed values fit 32-bit offsets
+        }
+        sl.r0 = r0; sl.rows = rows;
+        return rows;
+    };
+    auto launch = [&](size_t d, Slot &sl) {
+        Pipe &P = *pipes[d];
+        strsim_ctx_t *ctx = P.ctx;
+        hipStream_t stream = streams[d];
+        HIP_OR_FAIL(hipSetDevice(P.device));
+        const uint32_t *doff[2];
+        const uint8_t *dval[2];
+        uint64_t drows[2];
+        sl.direct = direct_call;
+        for (int s = 0; s < 2; ++s)
+            if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
+        for (int s = 0; s < 2; ++s) {
+            if (lit[s]) { doff[s] = lit_off_d[d]; dval[s] = lit_val_d[d]; drows[s] = 1; continue; }
+            drows[s] = sl.rows;
+            if (sl.direct) {
+                doff[s] = static_cast<const uint32_t *>(mapped(sl.h_off[s].p));
+                dval[s] = static_cast<const uint8_t *>(mapped(sl.h_val[s].p));
+                continue;
+            }
+            sl.d_off[s].reserve((sl.rows + 1) * sizeof(uint32_t));
+            sl.d_val[s].reserve(sl.bytes[s] + 64);
+            if (sl.as_views[s]) { // the views as they lie + the long strings over the link, the column made on the device
+                sl.d_views[s].reserve(sl.rows * sizeof(View) + 64);
+                sl.d_long[s].reserve(sl.long_span[s] + 64);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_views[s].p, sl.h_views[s].p, sl.rows * sizeof(View), hipMemcpyHostToDevice, stream));
+                if (sl.long_span[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_long[s].p, sl.h_long[s].p, sl.long_span[s], hipMemcpyHostToDevice, stream));
+                if (strsim_column_from_views_bounded(ctx, sl.d_views[s].p, sl.rows, static_cast<const uint8_t *>(sl.d_long[s].p), sl.long_span[s],
+                                                     static_cast<uint32_t *>(sl.d_off[s].p), static_cast<uint8_t *>(sl.d_val[s].p),
+                                                     sl.bytes[s] + 64, nullptr) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+                doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
+                dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
+                continue;
+            }
+            if (sl.lens8[s]) { // lengths over the link, offsets rebuilt on the device
+                sl.d_len[s].reserve(sl.rows + 16);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_len[s].p, sl.h_len[s].p, sl.rows, hipMemcpyHostToDevice, stream));
+                if (strsim_offsets_from_lengths(ctx, static_cast<const uint8_t *>(sl.d_len[s].p), sl.rows, static_cast<uint32_t *>(sl.d_off[s].p)) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+            } else {
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_off[s].p, sl.h_off[s].p, (sl.rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            }
+            if (sl.nseg[s] > 1) { // one-pass slice: one copy of the segments as they lie, then the gaps are closed on the device
+                sl.d_land[s].reserve(sl.span[s] + 64);
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_land[s].p, sl.h_val[s].p, sl.span[s], hipMemcpyHostToDevice, stream));
+                if (strsim_compact_segments(ctx, static_cast<const uint8_t *>(sl.d_land[s].p), static_cast<uint8_t *>(sl.d_val[s].p),
+                                                     sl.seg_src[s], sl.seg_dst[s], sl.seg_bytes[s], sl.nseg[s]) != STRSIM_OK)
+                    fail(strsim_last_error_message());
+            } else if (sl.bytes[s]) {
+                HIP_OR_FAIL(hipMemcpyAsync(sl.d_val[s].p, sl.h_val[s].p, sl.bytes[s], hipMemcpyHostToDevice, stream));
+            }
+            doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
+            dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
+        }
+        const bool via_slot = sl.direct || !out_pinned; // results pass through the slot's pinned buffer
+        if (via_slot) sl.h_out.reserve(sl.rows * sizeof(double));
+        if (!sl.direct) sl.d_out.reserve(sl.rows * sizeof(double));
+        double *res = static_cast<double *>(sl.direct ? mapped(sl.h_out.p) : sl.d_out.p);
+        // (a slice computed in place is a small call: one launch when the lane kernel leaves nothing behind)
+        if ((sl.direct ? strsim_pairs_device_small : strsim_pairs_device)(ctx, measure, doff[0], dval[0], drows[0], doff[1], dval[1], drows[1], res, sl.rows) != STRSIM_OK)
+            fail(strsim_last_error_message());
+        if (!sl.direct) {
+            // results come back right behind the kernels, on the copy stream: the next slice's H2D does not queue behind them
+            if (!sl.ev_kernels) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_kernels, hipEventDisableTiming));
+            if (!sl.ev_results) HIP_OR_FAIL(hipEventCreateWithFlags(&sl.ev_results, hipEventDisableTiming));
+            HIP_OR_FAIL(hipEventRecord(sl.ev_kernels, stream));
+            HIP_OR_FAIL(hipStreamWaitEvent(P.d2h, sl.ev_kernels, 0));
+            HIP_OR_FAIL(hipMemcpyAsync(out_pinned ? static_cast<void *>(out + sl.r0) : sl.h_out.p, sl.d_out.p, sl.rows * sizeof(double),
+                                       hipMemcpyDeviceToHost, P.d2h));
+            HIP_OR_FAIL(hipEventRecord(sl.ev_results, P.d2h));
+        }
+    };
+    // the slice's results have arrived (in the output column, or in the slot's pinned buffer): retire the call; copy if needed
+    auto finish = [&](size_t d, Slot &sl) {
+        Pipe &P = *pipes[d];
+        strsim_ctx_t *ctx = P.ctx;
+        PhaseTimer t1 = tm; // (same switch, own clock)
+        HIP_OR_FAIL(hipSetDevice(P.device));
+        t1.start();
+        if (sl.direct) {
+            if (strsim_ctx_synchronize(ctx) != STRSIM_OK) fail(strsim_last_error_message());
+        } else {
+            HIP_OR_FAIL(hipEventSynchronize(sl.ev_results));
+            // (the oldest call in flight on this pipeline is this slice's: slices are launched and finished in order)
+            if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the deferred slow-row and long-string passes
+        }
+        t1.stop(ptimes[d].t_wait);
+        const bool via_slot = sl.direct || !out_pinned;
+        if (strsim_ctx_last_late_rows(ctx) != 0 && !sl.direct) { // rows finished by a pass launched just now: fetch the column again
+            t1.start();
+            HIP_OR_FAIL(hipMemcpyAsync(via_slot ? sl.h_out.p : static_cast<void *>(out + sl.r0), sl.d_out.p, sl.rows * sizeof(double),
+                                       hipMemcpyDeviceToHost, streams[d]));
+            HIP_OR_FAIL(hipStreamSynchronize(streams[d]));
+            t1.stop(ptimes[d].t_d2h);
+        }
+        if (!via_slot) return;
+        tm.start();
+        const double *src = static_cast<const double *>(sl.h_out.p);
+        const unsigned Tc = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(sl.rows / 262144, 1));
+        fork_join(Tc, [&](unsigned t) {
+            const uint64_t i0 = sl.rows * t / Tc, i1 = sl.rows * (t + 1) / Tc;
+            memcpy(out + sl.r0 + i0, src + i0, (i1 - i0) * sizeof(double));
+        });
+        tm.stop(tm.t_copy);
+    };
+
+    // Slices ramp up from RAMP_ROWS and down again at the end, so that neither the first pack nor the last slice's trip is
+    // exposed at full size.  PCIe carries 35-41 B in and 8 B out per pair in the two directions at once, the host touches every
+    // byte once (pack) -- per 2 M-row slice 1.45 ms of link against 1.3 ms of packing.
+    // (knobs read per call: four getenv; tests shrink them to cut a small frame into many slices)
+    // (in round 1 cutting a 1 M-row call into four slices lost -- four small packs cost 1.3 ms instead of 0.6 ms; with both columns
+    // in one job and a pool that spins between jobs it wins, so only calls up to SINGLE_ROWS stay in one piece)
+    const uint64_t RAMP_ROWS = env_rows("POLARS_STRSIM_RAMP_ROWS", 512u << 10);   // first slice (tuning knobs)
+    const uint64_t FULL_ROWS = env_rows("POLARS_STRSIM_SLICE_ROWS", SLICE_ROWS);   // steady-state slice
+    const uint64_t GROW_PCT = env_rows("POLARS_STRSIM_RAMP_GROW_PCT", 150);         // slice k+1 = slice k x this / 100
+    const uint64_t SINGLE_ROWS = env_rows("POLARS_STRSIM_SINGLE_SLICE_ROWS", 300000); // calls up to here are not cut (1 M rows in four slices: 2.39 -> 2.06 ms)
+    uint64_t prev_rows = 0;
+    auto next_rows = [&](uint64_t r0) -> uint64_t {
+        const uint64_t left = n - r0;
+        if (direct_call || n <= SINGLE_ROWS) return left;     // small calls: one slice
+        const uint64_t ramp = n <= (2u << 20) ? RAMP_ROWS / 2 : RAMP_ROWS; // a mid-size call starts (and stays) smaller
+        uint64_t want = prev_rows == 0 ? ramp : std::min<uint64_t>(FULL_ROWS, prev_rows * GROW_PCT / 100);
+        want = std::min<uint64_t>(want, SLICE_ROWS);
+        if (left < 2 * want) want = std::max<uint64_t>(ramp, ((left / 2 + 65535) >> 16) << 16); // taper
+        if (left <= want + ramp / 2) want = left;                   // no crumbs
+        prev_rows = want;
+        return want;
+    };
+    // whatever goes wrong below (a failed launch, a string beyond 4 GiB in a later slice): nothing of this call may still be in
+    // flight when the error leaves the plugin -- the slots are reused by the next call and the output column is released
+    struct Drain {
+        std::vector<Pipe *> &pipes; bool armed = true;
+        ~Drain()
+        {
+            if (!armed) return;
+            for (Pipe *P : pipes) { (void)hipSetDevice(P->device); (void)strsim_ctx_synchronize(P->ctx); (void)hipStreamSynchronize(P->d2h); }
+        }
+    } drain{pipes};
+    uint64_t r0 = 0, launched = 0, finished = 0; // slices: i -> pipeline i % D, slot (i / D) % 3
+    auto slot_of = [&](uint64_t i) -> Slot & { return pipes[i % D]->slot[(i / D) % 3]; };
+    while (r0 < n) {
+        Slot &sl = slot_of(launched);
+        tm.start(); r0 += pack(sl, r0, next_rows(r0)); tm.stop(tm.t_pack); // overlaps the GPU work of the slices in flight
+        PhaseTimer t1 = tm;
+        t1.start(); launch(launched % D, sl); t1.stop(ptimes[launched % D].t_launch);
+        ++ptimes[launched % D].slices;
+        ++launched;
+        if (launched - finished > 2 * D) { finish(finished % D, slot_of(finished)); ++finished; } // two in flight per pipeline
+    }
+    for (; finished < launched; ++finished) finish(finished % D, slot_of(finished));
+    drain.armed = false;
+}
+
+// ---- output validity: AND of the input validities, built word by word on the packing pool ---------------------------
+// bits [bit0, bit0 + n) of `src` (LSB-first, Arrow) as 64-bit words of a stream that starts at bit 0: word k = bits
+// [64 k, 64 k + 64) of the range; bits past the range read as ones
+inline uint64_t bits_word(const uint8_t *src, int64_t bit0, uint64_t n, uint64_t k)
+{
+    const uint64_t first = 64 * k;
+    if (first >= n) return ~0ull;
+    const uint64_t take = std::min<uint64_t>(64, n - first);
+    const int64_t b = bit0 + (int64_t)first;
+    const uint8_t *p = src + (b >> 3);
+    const unsigned sh = (unsigned)(b & 7);
+    uint64_t w = 0;
+    const unsigned nbytes = (unsigned)((sh + take + 7) >> 3); // <= 9
+    for (unsigned q = 0; q < nbytes && q < 8; ++q) w |= (uint64_t)p[q] << (8 * q);
+    w >>= sh;
+    if (nbytes == 9) w |= (uint64_t)p[8] << (64 - sh);
+    if (take < 64) w |= ~0ull << take;
+    return w;
+}
+
+// AND the validity of rows [r0, r1) of `c` into dst, whose bit 0 is row r0 (r0 a multiple of 64): whole words only
+void and_validity(const Column &c, uint64_t r0, uint64_t r1, uint64_t *dst)
+{
+    if (!c.any_null || r0 >= r1) return;
+    for (size_t ci = chunk_of(c, r0); ci < c.chunks.size() && c.chunks[ci].row0 < r1; ++ci) {
+        const Chunk &k = c.chunks[ci];
+        if (!k.nulls) continue;
+        const uint64_t lo = std::max(r0, k.row0), hi = std::min(r1, k.row0 + (uint64_t)k.a->length); // rows of this chunk in range
+        // destination words that hold rows [lo, hi): the chunk's bits arrive shifted by (lo - r0) & 63
+        const uint64_t dbit = lo - r0;
+        const int64_t sbit = k.a->offset + (int64_t)(lo - k.row0);
+        const uint64_t cnt = hi - lo;
+        // head: up to the next destination word boundary, then whole source words, shifted in
+        uint64_t done = 0;
+        while (done < cnt) {
+            const uint64_t db = dbit + done;
+            const unsigned dsh = (unsigned)(db & 63);
+            const uint64_t take = std::min<uint64_t>(64 - dsh, cnt - done);
+            uint64_t w = bits_word(k.nulls, sbit + (int64_t)done, take, 0); // ones beyond `take`
+            // place at dsh; ones elsewhere
+            const uint64_t placed = (w << dsh) | (dsh ? (~0ull >> (64 - dsh)) : 0ull);
+            dst[db >> 6] &= placed;
+            done += take;
+        }
+    }
+}
+
+// validity words of rows [0, n) = AND of the non-literal inputs' validities, 64 rows at a time on `T` packing threads (their row
+// ranges are cut at multiples of 64, so no two threads share a word); bits past row n are zero.  The value under a null slot is
+// set to 0.0 in `out` (never observable; keeps the column deterministic).  Returns the null count.
+int64_t build_validity(const Column (&col)[2], const bool (&lit)[2], uint64_t n, bool all_null, unsigned T, uint64_t *vw, double *out)
+{
+    const uint64_t nwords = (n + 63) / 64;
+    if (all_null) {
+        memset(vw, 0, nwords * 8);
+        return (int64_t)n;
+    }
+    const unsigned Tv = (unsigned)std::min<uint64_t>(std::max(1u, T), std::max<uint64_t>(nwords / 4096, 1));
+    std::vector<int64_t> nulls(Tv, 0);
+    fork_join(Tv, [&](unsigned t) {
+        const uint64_t w0 = nwords * t / Tv, w1 = nwords * (t + 1) / Tv;
+        const uint64_t r0 = w0 * 64, r1 = std::min<uint64_t>(w1 * 64, n);
+        for (uint64_t w = w0; w < w1; ++w) vw[w] = ~0ull;
+        for (int s = 0; s < 2; ++s)
+            if (!lit[s]) and_validity(col[s], r0, r1, vw + w0);
+        int64_t cnt = 0;
+        for (uint64_t w = w0; w < w1; ++w) {
+            uint64_t word = vw[w];
+            if (w == nwords - 1 && (n & 63)) word &= ~0ull >> (64 - (n & 63)); // (bits past the column: zero)
+            vw[w] = word;
+            uint64_t zeros = ~word;
+            if (w == nwords - 1 && (n & 63)) zeros &= ~0ull >> (64 - (n & 63));
+            cnt += __builtin_popcountll(zeros);
+            if (out)
+                while (zeros) {
+                    out[w * 64 + (uint64_t)__builtin_ctzll(zeros)] = 0.0;
+                    zeros &= zeros - 1;
+                }
+        }
+        nulls[t] = cnt;
+    });
+    int64_t total = 0;
+    for (int64_t c : nulls) total += c;
+    return total;
+}

@@ -13,6 +13,7 @@
 //   encode: f64[n] -> u16[n] (+ exceptions)    hash lookup keyed by the f64 bit pattern (open addressing, L2-resident)
 //   decode: u16[n] -> f64[n]                   table[code]; 0xFFFF rows are left for the exception patch
 #include <hip/hip_runtime.h>
+#include "strsim_bounds.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view_column(const uint4 *__res
         __syncthreads();
         run += strip;
         if (r < rows) {
+            STRSIM_CHECK_INDEX(K_VIEWS, 1, r, r + 1u, rows + 1u); // (lab: offsets[rows + 1])
             off[r + 1] = (uint32_t)(at + len);
             const bool in_values = at + len <= cap;
             const bool in_longs = len <= 12u || (longs != nullptr && (uint64_t)v.w + len <= long_bytes);
@@ -441,6 +443,8 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view_column(const uint4 *__res
                 continue;
             }
             uint8_t *__restrict__ const dst = values + at;
+            STRSIM_CHECK_RANGE(K_VIEWS, 2, r, at + len, 0, cap);                                      // the packed values
+            if (len > 12u) STRSIM_CHECK_RANGE(K_VIEWS, 3, r, (unsigned long long)v.w + len, 0, long_bytes); // the long strings
             if (len <= 12u) { // the string is in the view: whole dwords, then the tail byte by byte
                 if (len >= 4u) *reinterpret_cast<u32_u *>(dst) = v.y;
                 if (len >= 8u) *reinterpret_cast<u32_u *>(dst + 4) = v.z;
@@ -748,5 +752,18 @@ int strsim_codec_decode_packed(strsim_ctx_t *ctx, const strsim_codec_t *c, const
     HIP_TRY(hipGetLastError());
     return STRSIM_OK;
 }
+
+#if STRSIM_BOUNDS_ON
+// lab build only: the address-check record of this translation unit (the view kernels), read and cleared like strsim_debug_bounds_kernels
+__attribute__((visibility("default"))) int strsim_debug_bounds_codec(unsigned long long *dst)
+{
+    strsim::bounds::Record r{};
+    hipError_t e = hipMemcpyFromSymbol(&r, HIP_SYMBOL(strsim::bounds::g_rec), sizeof(r), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    dst[0] = r.hits; dst[1] = r.site; dst[2] = r.row; dst[3] = r.value; dst[4] = r.lo; dst[5] = r.hi;
+    const strsim::bounds::Record z{};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(strsim::bounds::g_rec), &z, sizeof(z), 0, hipMemcpyHostToDevice);
+}
+#endif
 
 } // extern "C"

@@ -86,6 +86,9 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         else (&s_word[0][0])[(uint32_t)q * LIT_BLOCK + tid] = 0xFFFFFFFFu;
     }
     const uint32_t totalC = load_invariant(offC + n);
+#if STRSIM_BOUNDS_ON
+    const uint32_t firstC = load_invariant(offC); // (lab: where the column's bytes begin)
+#endif
     const uint32_t lit0 = load_invariant(offL), litl = load_invariant(offL + 1) - lit0;
     if (wv == 0u) {
         uint32_t w[8];
@@ -123,7 +126,13 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         const uint32_t dst = ldsOff + buf * (uint32_t)((B + 4) * 4);
 #pragma unroll
         for (int it = 0; it < RPT; ++it)
-            if (tid + (uint32_t)it * LIT_BLOCK <= cnt) lds_dma_b32(p + it * LIT_BLOCK, tid4, dst + 4u * ((uint32_t)it * LIT_BLOCK + wvu * 64u));
+            if (tid + (uint32_t)it * LIT_BLOCK <= cnt) {
+                STRSIM_CHECK_INDEX(K_LIT, 1, row, row + (uint64_t)it * LIT_BLOCK + tid, n + 1u); // offsets[..] of n + 1
+                STRSIM_CHECK_INDEX(K_LIT, 2, row, (uint32_t)it * LIT_BLOCK + tid, B + 4);        // -> s_off[buf][..] of B + 4
+                STRSIM_CHECK_INDEX(K_LIT, 3, row, buf, 3);
+                lds_dma_b32(p + it * LIT_BLOCK, tid4, dst + 4u * ((uint32_t)it * LIT_BLOCK + wvu * 64u));
+            }
+        if (tid == 0u && cnt == (uint32_t)B) STRSIM_CHECK_INDEX(K_LIT, 4, row, row + (uint64_t)B, n + 1u);
         if (tid == 0u && cnt == (uint32_t)B) lds_dma_b32(p + B, tid4, dst + 4u * (uint32_t)B);
     };
     // the block that starts at `row` with its offsets in s_off[buf]: as many of the next chunks as fit the staging area
@@ -150,8 +159,12 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         const uint8_t *const g = valC + base - mis;
 #pragma unroll
         for (int it = 0; it < LIT_DMA_ITERS; ++it)
-            if (tid + (uint32_t)it * LIT_BLOCK < chunks)
+            if (tid + (uint32_t)it * LIT_BLOCK < chunks) {
+                STRSIM_CHECK_COLUMN(K_LIT, 10, base, g + 16 * it * LIT_BLOCK + tid16, 16, valC, firstC, totalC); // 16 bytes of the column
+                STRSIM_CHECK_RANGE(K_LIT, 11, base, 16u * ((uint32_t)it * LIT_BLOCK + tid) + 16u, 0, LIT_COL);   // -> this buffer
                 lds_dma_b128(g + 16 * it * LIT_BLOCK, tid16, ldsBytes + buf * (uint32_t)LIT_COL + 16u * ((uint32_t)it * LIT_BLOCK + wvu * 64u));
+            }
+        if (tid < 2u) STRSIM_CHECK_RANGE(K_LIT, 12, base, (chunks << 4) + tid * 16u + 16u, 0, LIT_COL);
         if (tid < 2u) *reinterpret_cast<uint4 *>(&s_bytes[buf][(chunks << 4) + tid * 16u]) = make_uint4(0u, 0u, 0u, 0u);
         tail_lo = left;
         tail_hi = chunks << 4;
@@ -196,6 +209,8 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
                 if (LEV) v = 1.0 - t0[q];
                 else if (!undone) v = stage_epilogue<M1>(pk[q], t0[q], t1[q], t2[q]);
                 const unsigned long long left = __ballot(undone && valid);
+                if (valid) STRSIM_CHECK_INDEX(K_LIT, 20, r0 + i, r0 + i, n);
+                if (valid && lane == 0u) STRSIM_CHECK_INDEX(K_LIT, 21, r0 + i, (r0 >> 6) + (i >> 6), nchunks);
                 if (valid && !undone) outb[i] = v;
                 if (lane == 0u && valid) {
                     maskb[i >> 6] = left;
@@ -223,7 +238,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         // ---- bytes(j) and offsets(j+1) have landed; everybody is done with block j-1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tail_lo < tail_hi && tid == (((tail_hi >> 4) - 1u) & (uint32_t)(LIT_BLOCK - 1)))
-            for (uint32_t b = tail_lo; b < tail_hi; ++b) s_bytes[bb][b] = 0;
+            for (uint32_t b = tail_lo; b < tail_hi; ++b) { STRSIM_CHECK_INDEX(K_LIT, 13, row0, b, LIT_COL); s_bytes[bb][b] = 0; }
         lds_barrier();
         // ---- block j+1: cut it, start its bytes and the offsets of block j+2
         const uint64_t next_row0 = row0 + rows;
@@ -241,12 +256,13 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
         for (uint32_t r = wv; r * 64u < rows; r += LIT_WAVES) {
             const uint32_t i = r * 64u + lane;
             const bool have = i < rows;
+            STRSIM_CHECK_INDEX(K_LIT, 30, row0, have ? i + 1u : 0u, B + 4);
             const uint32_t o0 = s_off[ob][have ? i : 0u], o1 = s_off[ob][have ? i + 1u : 0u];
             const uint32_t lp = o1 - o0, p0 = mis + (o0 - base);
             // mine: a column string of <= 32 bytes inside what was staged (the window behind it may hold anything)
             bool fast = have && lit_ok && lp <= 32u && p0 + lp <= staged;
             uint32_t wp[8];
-            stage_window(&s_bytes[bb][0], fast ? p0 : 0u, wp);
+            stage_window(&s_bytes[bb][0], fast ? p0 : 0u, wp, (uint32_t)LIT_COL, STRSIM_BOUNDS_ON ? 2u : 0u);
             uint32_t any;
             const uint32_t vary = window_vary(wt, wp, any);
             if (any & 0x80u) fast = false;
@@ -270,6 +286,7 @@ k_lane_lit(const uint32_t *__restrict__ offC, const uint8_t *__restrict__ valC, 
                     }
                     code = lp ? dist * (uint32_t)QTAB_N + (litl > lp ? litl : lp) : (uint32_t)QTAB_N + 1u; // an empty column string: 0.0
                 }
+                if (fast) STRSIM_CHECK_INDEX(K_LIT, 31, row0, i, B);
                 if (fast) s_code[LEV ? bb : 0u][LEV ? i : 0u] = (uint16_t)code;
             } else {
                 // text = the literal, pattern = the column string: exactly litl columns for every

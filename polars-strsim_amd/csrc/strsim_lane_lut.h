@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "strsim_bounds.h"
 #include "strsim_lane_core.h"
 
 namespace strsim {
@@ -83,6 +84,8 @@ STRSIM_HD uint32_t lut_read(const EqLut &t, uint32_t idx, int byte)
 #if defined(__HIP_DEVICE_COMPILE__)
     // v_perm_b32 {S0 = idx (bytes 4..7), S1 = lane4 (bytes 0..3)}: [lane4.b0, idx.b<byte>, 0, 0]
     const uint32_t addr = __builtin_amdgcn_perm(idx, t.lane4, 0x0C0C0000u | ((4u + (uint32_t)byte) << 8));
+    // (lab: inside this wave's twelve table entries)
+    STRSIM_CHECK_RANGE(K_STAGE, 50, ~0ull, addr, (t.krep & 0xFFu) << 8, ((t.krep & 0xFFu) << 8) + (uint32_t)LUT_WAVE_BYTES - 4u);
     return lut_lds_read(addr);
 #else
     return t.tab[(idx >> (8 * byte)) & 0xFFu];

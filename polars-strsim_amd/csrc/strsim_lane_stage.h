@@ -97,7 +97,7 @@ template <bool TABLES, bool LONG = false> struct StageGeom {
     static constexpr int CAP = LONG ? STRSIM_STAGE_CAP_LONG : (TABLES ? STRSIM_STAGE_CAP_LUT : STRSIM_STAGE_CAP);
     static constexpr int COL = CAP + 96;              // LDS bytes per column: + 32 bytes behind the block, a chunk's rounding, 32 zeros
     static constexpr int DMA_ITERS = (CAP + 48 + 16 * STAGE_BLOCK - 1) / (16 * STAGE_BLOCK);
-    static_assert(CAP % 16 == 0 && 2 * COL + 64 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
+    static_assert(CAP % 16 == 0 && 2 * COL + 64 + 16 <= 65536, "staging area: whole wave-instructions, 16-bit LDS offsets");
 };
 constexpr int STAGE_BSH = STRSIM_STAGE_BUCKET_SHIFT;  // buckets of 2^BSH column counts
 constexpr int STAGE_NBK = (32 >> STAGE_BSH) + 1;      // + one for the rows this kernel leaves to the later ones
@@ -147,9 +147,12 @@ constexpr uint32_t STAGE_DEAD = 1u << 31;
 // 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7]: nine dwords from the dword-aligned address below (56 LDS
 // cycles per 64 lanes) + eight v_alignbyte_b32.  (gfx950 serves a wide LDS read that is not naturally aligned one lane at a time:
 // two ds_read_b128 at the byte address cost 129 LDS cycles, bench_support/micro/lds_window.hip; cfg2 1.636 vs 1.587 ms.)
-__device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, uint32_t (&w)[8])
+__device__ __forceinline__ void stage_window(const uint8_t *base, uint32_t at, uint32_t (&w)[8], uint32_t lds_bytes = 0u, uint32_t who = 0u)
 {
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    (void)lds_bytes; (void)who;
+    if (who == 1u) STRSIM_CHECK_RANGE(K_STAGE, 40, ~0ull, (at & ~3u) + 36u, 0, lds_bytes); // (nine dwords from the aligned address below `at`)
+    if (who == 2u) STRSIM_CHECK_RANGE(K_LIT, 40, ~0ull, (at & ~3u) + 36u, 0, lds_bytes);
     const uint8_t *q = base + (at & ~3u);
     const u32x4_a4 lo = *reinterpret_cast<const u32x4_a4 *>(q);
     const u32x4_a4 hi = *reinterpret_cast<const u32x4_a4 *>(q + 16);
@@ -306,17 +309,20 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
         uint32_t code;
         if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        if (fast) STRSIM_CHECK_INDEX(K_STAGE, 42, ~0ull, idx, STAGE_ROWS);
         if (fast) s_code[idx] = (uint16_t)code;
     } else if (MEASURE == ALL_MEASURES) {
         unsigned long long pk;
         if (wide) pk = stage_all_ints<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         else pk = stage_all_ints<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        if (fast) STRSIM_CHECK_INDEX(K_STAGE, 43, ~0ull, idx, STAGE_ROWS);
         if (fast) reinterpret_cast<unsigned long long *>(s_val)[idx] = pk;
     } else {
         // the measure's integers, 32 bits per row; its f64 epilogue runs in the store phase (stage_epilogue)
         uint32_t pk;
         if (wide) pk = stage_ints<MEASURE, 7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
         else pk = stage_ints<MEASURE, 5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        if (fast) STRSIM_CHECK_INDEX(K_STAGE, 44, ~0ull, idx, STAGE_ROWS);
         if (fast) s_word[idx] = pk;
     }
 }
@@ -340,7 +346,10 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     static_assert(!LUT || (B <= 128 * STAGE_WAVES && LUT_WAVE_BYTES == 3072), "descriptor slices: 128 rows behind each wave's tables");
     __shared__ __attribute__((aligned(4096))) uint8_t s_lut[LUT ? 4096 * STAGE_WAVES : 16];
     __shared__ uint2 s_desc_own[LUT ? 1 : B];
-    __shared__ __attribute__((aligned(4096))) uint8_t s_bytes[2 * STAGE_COL + 64];
+    // (+ 16: a window is read as NINE dwords from the aligned address below it -- the ninth only feeds the alignment shift -- and the
+    //  second literal's window starts 32 bytes before the end of the 64: its ninth dword lay 4 bytes past the array.  [r5] Found by the
+    //  bounds-checked lab build (csrc/strsim_bounds.h) on a one-row x one-row call; the value was never used, the read was out of the array.)
+    __shared__ __attribute__((aligned(4096))) uint8_t s_bytes[2 * STAGE_COL + 64 + 16];
     auto desc_at = [&](uint32_t p) -> uint2 * { // descriptor of position p of the length order
         if (LUT) return reinterpret_cast<uint2 *>(s_lut + ((p >> 7) << 12) + LUT_WAVE_BYTES + ((p & 127u) << 3));
         return s_desc_own + p;
@@ -369,6 +378,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
     }
 
     const uint32_t totalA = load_invariant(offA + rowsA), totalB = load_invariant(offB + rowsB);
+#if STRSIM_BOUNDS_ON
+    const uint32_t firstA = load_invariant(offA), firstB = load_invariant(offB); // (lab: where the columns' bytes begin)
+#endif
     const bool bcastA = rowsA == 1, bcastB = rowsB == 1; // a one-row side is the literal (strsim.rs:48-52, :61-66)
     const uint32_t litA0 = bcastA ? load_invariant(offA) : 0u, litB0 = bcastB ? load_invariant(offB) : 0u;
     const uint32_t litAlen = bcastA ? totalA - litA0 : 0u, litBlen = bcastB ? totalB - litB0 : 0u;
@@ -439,11 +451,17 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
             if (tid + (uint32_t)it * STAGE_BLOCK <= cnt) {
+                // (lab: offsets[row + it * 256 + tid] of an array of rows + 1 entries -> s_off[side][it * 256 + tid] of B + 4)
+                if (!bcastA) STRSIM_CHECK_INDEX(K_STAGE, 1, row, row + (uint64_t)it * STAGE_BLOCK + tid, rowsA + 1u);
+                if (!bcastB) STRSIM_CHECK_INDEX(K_STAGE, 2, row, row + (uint64_t)it * STAGE_BLOCK + tid, rowsB + 1u);
+                STRSIM_CHECK_INDEX(K_STAGE, 3, row, (uint32_t)it * STAGE_BLOCK + tid, B + 4);
                 if (!bcastA) lds_dma_b32(pa + it * STAGE_BLOCK, tid4, ldsOffA + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
                 if (!bcastB) lds_dma_b32(pb + it * STAGE_BLOCK, tid4, ldsOffB + 4u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
             }
         }
         if (tid == 0u && cnt == (uint32_t)B) { // the offset behind the last row of a full block
+            if (!bcastA) STRSIM_CHECK_INDEX(K_STAGE, 4, row, row + (uint64_t)B, rowsA + 1u);
+            if (!bcastB) STRSIM_CHECK_INDEX(K_STAGE, 5, row, row + (uint64_t)B, rowsB + 1u);
             if (!bcastA) lds_dma_b32(pa + B, tid4, ldsOffA + 4u * (uint32_t)B);
             if (!bcastB) lds_dma_b32(pb + B, tid4, ldsOffB + 4u * (uint32_t)B);
         }
@@ -488,6 +506,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 // 1.0 - dist / den (strsim.rs:160) with the quotient from the context's table of integer quotients: the
                 // same IEEE division, done once per context on the host instead of once per row (the table is 34 KB,
                 // L2-resident; it used to be 8.5 KB of LDS per workgroup = one workgroup per CU less)
+                STRSIM_CHECK_INDEX(K_STAGE, 12, r0, (uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q], QTAB_N * QTAB_N);
                 t0[q] = qtab[(uint32_t)pk[q] == 0xFFFFu ? 0u : (uint32_t)pk[q]];
             } else if (JARO_LIKE) {
                 const uint32_t lo = (uint32_t)pk[q], hi = (uint32_t)(pk[q] >> 32);
@@ -495,6 +514,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t la = ALL ? (((lo >> 27) & 31u) | ((hi & 1u) << 5)) : ((lo >> 12) & 63u);
                 const uint32_t lb = ALL ? ((hi >> 1) & 63u) : ((lo >> 18) & 63u);
                 const uint32_t h = t >> 1;
+                STRSIM_CHECK_INDEX(K_STAGE, 13, r0, m * (uint32_t)QTAB_N + la, QTAB_N * QTAB_N);
+                STRSIM_CHECK_INDEX(K_STAGE, 14, r0, m * (uint32_t)QTAB_N + lb, QTAB_N * QTAB_N);
                 t0[q] = qtab[m * (uint32_t)QTAB_N + la];
                 t1[q] = qtab[m * (uint32_t)QTAB_N + lb];
                 t2[q] = qtab[(m > h ? m - h : 0u) * (uint32_t)QTAB_N + m];
@@ -528,6 +549,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 }
                 const bool valid = i < rows;
                 const unsigned long long left = __ballot(undone && valid);
+                if (valid) STRSIM_CHECK_INDEX(K_STAGE, 10, r0 + i, r0 + i, n);                  // the result column
+                if (lane == 0u && valid) STRSIM_CHECK_INDEX(K_STAGE, 11, r0 + i, (r0 >> 6) + (i >> 6), nchunks); // the mask word
                 if (valid && !undone) {
                     if (ALL) {
 #pragma unroll
@@ -592,16 +615,25 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         const uint32_t leftA = totalA - baseA + misA, leftB = totalB - baseB + misB; // column bytes from the aligned start on
         const uint32_t chunksA = bcastA ? 0u : ((stagedA + 32u < leftA ? stagedA + 32u : leftA) + 15u) >> 4;
         const uint32_t chunksB = bcastB ? 0u : ((stagedB + 32u < leftB ? stagedB + 32u : leftB) + 15u) >> 4;
+        if (tid < 2u) STRSIM_CHECK_RANGE(K_STAGE, 20, row0, (chunksA << 4) + tid * 16u + 16u, 0, COLB);
+        else if (tid < 4u) STRSIM_CHECK_RANGE(K_STAGE, 21, row0, COLB + (chunksB << 4) + (tid - 2u) * 16u + 16u, 0, sizeof(s_bytes));
         if (tid < 2u) *reinterpret_cast<uint4 *>(s_bytes + (chunksA << 4) + tid * 16u) = make_uint4(0u, 0u, 0u, 0u);
         else if (tid < 4u) *reinterpret_cast<uint4 *>(s_bytes + COLB + (chunksB << 4) + (tid - 2u) * 16u) = make_uint4(0u, 0u, 0u, 0u);
         {
             const uint8_t *__restrict__ const gA = valA + baseA - misA, *__restrict__ const gB = valB + baseB - misB;
 #pragma unroll
             for (int it = 0; it < STAGE_DMA_ITERS; ++it) {
-                if (tid + (uint32_t)it * STAGE_BLOCK < chunksA)
+                if (tid + (uint32_t)it * STAGE_BLOCK < chunksA) {
+                    // (lab: 16 bytes of the column by the over-read contract -> 16 bytes of column a's staging area)
+                    STRSIM_CHECK_COLUMN(K_STAGE, 22, row0, gA + 16 * it * STAGE_BLOCK + tid16, 16, valA, firstA, totalA);
+                    STRSIM_CHECK_RANGE(K_STAGE, 23, row0, 16u * ((uint32_t)it * STAGE_BLOCK + tid) + 16u, 0, COLB);
                     lds_dma_b128(gA + 16 * it * STAGE_BLOCK, tid16, ldsBytes + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
-                if (tid + (uint32_t)it * STAGE_BLOCK < chunksB)
+                }
+                if (tid + (uint32_t)it * STAGE_BLOCK < chunksB) {
+                    STRSIM_CHECK_COLUMN(K_STAGE, 24, row0, gB + 16 * it * STAGE_BLOCK + tid16, 16, valB, firstB, totalB);
+                    STRSIM_CHECK_RANGE(K_STAGE, 25, row0, COLB + 16u * ((uint32_t)it * STAGE_BLOCK + tid) + 16u, 0, sizeof(s_bytes));
                     lds_dma_b128(gB + 16 * it * STAGE_BLOCK, tid16, ldsBytes + COLB + 16u * ((uint32_t)it * STAGE_BLOCK + wvu * 64u));
+                }
             }
         }
         STAGE_STAMP(0);
@@ -611,6 +643,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const uint32_t i = (uint32_t)RPT * tid + (uint32_t)q;
+                STRSIM_CHECK_INDEX(K_STAGE, 30, row0, i + 1u, B + 4);
                 const bool have = i < rows;
                 const uint32_t a0 = bcastA ? 0u : s_off[0][i] - baseA, b0 = bcastB ? 0u : s_off[1][i] - baseB;
                 const uint32_t la8 = bcastA ? litAlen : s_off[0][i + 1u] - s_off[0][i];
@@ -640,6 +673,7 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
             for (int q = 0; q < RPT; ++q) {
                 const uint32_t base = __shfl(exc, skey[q], 32);
                 const uint32_t p = base + srank[q]; // position in length order
+                STRSIM_CHECK_INDEX(K_STAGE, 31, row0, p, B);
                 *desc_at(p) = make_uint2(sd0[q], sd1[q]);
             }
             nmine = uniform(__shfl(exc, NBK - 1, 32));
@@ -651,9 +685,9 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
         // another allocation) and a high bit in it would send the block's last rows to the slow kernels at random.  The lane
         // that copied that chunk zeroes its tail (its own copy has landed; the barrier publishes the zeros).
         if (!bcastA && leftA < (chunksA << 4) && tid == ((chunksA - 1u) & (uint32_t)(STAGE_BLOCK - 1)))
-            for (uint32_t b = leftA; b < (chunksA << 4); ++b) s_bytes[b] = 0;
+            for (uint32_t b = leftA; b < (chunksA << 4); ++b) { STRSIM_CHECK_INDEX(K_STAGE, 32, row0, b, COLB); s_bytes[b] = 0; }
         if (!bcastB && leftB < (chunksB << 4) && tid == ((chunksB - 1u) & (uint32_t)(STAGE_BLOCK - 1)))
-            for (uint32_t b = leftB; b < (chunksB << 4); ++b) s_bytes[COLB + b] = 0;
+            for (uint32_t b = leftB; b < (chunksB << 4); ++b) { STRSIM_CHECK_INDEX(K_STAGE, 33, row0, COLB + b, sizeof(s_bytes)); s_bytes[COLB + b] = 0; }
         lds_barrier();
         STAGE_STAMP(5);
         if (tid < 32u) s_cnt[tid] = 0u; // read by sortB above, next used by sortA behind barrier G
@@ -683,10 +717,11 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t first = hi >= 64u ? hi - 64u : 0u;   // its first position
                 const uint32_t in_round = hi - first;               // (>= 1)
                 __builtin_amdgcn_s_setprio(1); // descriptor + window fetch ahead of the waves that grind columns
+                STRSIM_CHECK_INDEX(K_STAGE, 41, row0, first + lane, B);
                 const uint2 d = *desc_at(first + lane);
                 uint32_t wt[8], wp[8];
-                stage_window(s_bytes, d.x & 0xFFFFu, wt);
-                stage_window(s_bytes, d.x >> 16, wp);
+                stage_window(s_bytes, d.x & 0xFFFFu, wt, (uint32_t)sizeof(s_bytes), STRSIM_BOUNDS_ON ? 1u : 0u);
+                stage_window(s_bytes, d.x >> 16, wp, (uint32_t)sizeof(s_bytes), STRSIM_BOUNDS_ON ? 1u : 0u);
     #if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STAMPS)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     #endif

@@ -50,3 +50,28 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _address_checks_of_the_lab_build(request):
+    """With the bounds-checked lab build selected (STRSIM_AMD_LIB = a library made with EXTRA="-DSTRSIM_LAB -DSTRSIM_BOUNDS",
+    bench_support/jobs/r5_bounds_fuzz.sh) every GPU test also asserts that no kernel formed an address outside its launch's extents.
+    The product library has no such symbols: nothing happens."""
+    yield
+    if "gpu" not in request.keywords or not os.environ.get("STRSIM_AMD_LIB"):
+        return
+    import ctypes as C
+    import strsim_amd as S
+    L = S.lib()
+    if not hasattr(L, "strsim_debug_bounds_kernels"):
+        return
+    import torch
+    torch.cuda.synchronize()
+    for unit in ("kernels", "codec"):
+        f = getattr(L, "strsim_debug_bounds_" + unit)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        rec = (C.c_ulonglong * 6)()
+        assert f(rec) == 0
+        assert rec[0] == 0, "address out of bounds in the %s unit: hits %d, kernel %d site %d, row %d, value %#x not in [%#x, %#x]" % (
+            unit, rec[0], rec[1] >> 32, rec[1] & 0xFFFFFFFF, rec[2], rec[3], rec[4], rec[5])

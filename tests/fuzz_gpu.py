@@ -26,6 +26,28 @@ ALPHABETS = {
 }
 CLASSES = [(0, 8, 20000), (0, 40, 20000), (20, 140, 6000), (100, 1100, 600), (900, 2600, 60), (0, 1100, 1500)]
 ctx = S.Context(0)
+
+
+def bounds_violations():
+    """Lab build only (EXTRA="-DSTRSIM_LAB -DSTRSIM_BOUNDS", selected with STRSIM_AMD_LIB): the kernels' address-check records, read and
+    cleared -> [(unit, hits, kernel, site, row, value, lo, hi)] of the units that saw a violation.  The product library has no such
+    symbols: []."""
+    import ctypes as C
+    out = []
+    for unit in ("kernels", "codec"):
+        f = getattr(S.lib(), "strsim_debug_bounds_" + unit, None)
+        if f is None:
+            continue
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        rec = (C.c_ulonglong * 6)()
+        assert f(rec) == 0
+        if rec[0]:
+            out.append((unit, rec[0], rec[1] >> 32, rec[1] & 0xFFFFFFFF, rec[2], hex(rec[3]), hex(rec[4]), hex(rec[5])))
+    return out
+
+
+CHECKED = hasattr(S.lib(), "strsim_debug_bounds_kernels")
 t_end = time.time() + budget
 rounds = 0
 while time.time() < t_end:
@@ -45,6 +67,11 @@ while time.time() < t_end:
     if os.environ.get("STRSIM_FUZZ_VERBOSE"):  # (a GPU fault kills the process: say what was running)
         print(f"round {rounds + 1}: {measure} {name} [{lo},{hi}] n={n} literal={side} bytes a={len(av)} b={len(bv)}", flush=True)
     got = ctx.pairs_host(measure, ao, av, bo, bv)
+    viol = bounds_violations()
+    if viol:
+        print(f"ADDRESS OUT OF BOUNDS round {rounds + 1}: {measure} {name} [{lo},{hi}] n={n} literal={side} seed={seed}: "
+              f"(unit, hits, kernel, site, row, value, lo, hi) = {viol}")
+        sys.exit(2)
     A2 = A * n if len(A) == 1 else A
     B2 = B * n if len(B) == 1 else B
     exp = O.batch_strings(measure, A2, B2, 16)
@@ -55,4 +82,4 @@ while time.time() < t_end:
         print(f"MISMATCH round {rounds}: {measure} {name} [{lo},{hi}] n={n} literal={side}: {bad.size} rows; row {i}: "
               f"a={A2[i]!r} b={B2[i]!r} got={got[i]!r} exp={exp[i]!r}")
         sys.exit(1)
-print(f"fuzz ok: {rounds} rounds in {budget:.0f} s (seed {seed})")
+print(f"fuzz ok: {rounds} rounds in {budget:.0f} s (seed {seed}){', every address checked (lab build)' if CHECKED else ''}")
