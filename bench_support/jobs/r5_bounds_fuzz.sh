@@ -6,10 +6,10 @@
 SECS=${1:-75}
 export STRSIM_AMD_LIB=$(pwd)/ab_builds/libbounds.so
 OUT=gpurun_out/r5_bounds_fuzz.txt; mkdir -p gpurun_out; : > $OUT
-for seed in 5004 6001 6002 6003 6004 6005 6006 6007 $(date +%s); do
+for seed in 5004 7001 7002 7003 7004 7005 7006 7007 $(date +%s); do
   python tests/fuzz_gpu.py $SECS $seed 2>&1 | grep -v amdgpu.ids | tail -2 | tee -a $OUT
 done
-python -m pytest tests/test_gpu_parity.py tests/test_plugin_abi_gpu.py -m gpu -x -q 2>&1 | tail -3 | tee -a $OUT
+python -m pytest tests/test_gpu_parity.py tests/test_plugin_abi_gpu.py tests/test_plugin_configs_gpu.py tests/test_gpu_hypothesis.py -m gpu -q 2>&1 | tail -3 | tee -a $OUT
 python - <<'PY' 2>&1 | tee -a $OUT
 import sys
 sys.path[:0] = ["polars-strsim_amd", "tests"]

@@ -118,18 +118,21 @@ __global__ __launch_bounds__(64) void k_transpose(const uint32_t *__restrict__ b
         for (int p = 0; p < 32; ++p) {
             uint32_t w[8], P[NP];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) w[d] = bytes[((blockIdx.x * 32 + p) * 8 + d) * 64 + lane] ^ fold;
+            for (int d = 0; d < 8; ++d) w[d] = bytes[(p * 8 + d) * 64 + lane] ^ fold; // (every wave reads the same 64 KB: cache-resident -- the issue cost is what is measured)
             build_planes<NP>(w, P);
 #pragma unroll
             for (int k = 0; k < NP; ++k) M[k][p] = P[k];
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) transpose32(M[k]);
+        // (in a real kernel the planes would stay in registers / LDS: folded into one word here instead of 40 KB of stores per wave)
+        uint32_t x = 0u;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
 #pragma unroll
-            for (int i = 0; i < 32; ++i) planes[((blockIdx.x * 32 + i) * NP + k) * 64 + lane] = M[k][i];
-        fold = M[0][0] & (it == 0x7FFFFFFF ? 1u : 0u);
+            for (int i = 0; i < 32; ++i) x = bitop3<0x96>(x, M[k][i], (uint32_t)(i * NP + k));
+        planes[blockIdx.x * 64 + lane] = x;
+        fold = x & (it == 0x7FFFFFFF ? 1u : 0u);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) clk[blockIdx.x] = t1 - t0;

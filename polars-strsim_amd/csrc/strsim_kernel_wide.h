@@ -291,7 +291,7 @@ __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint
 // W: words of the masks (by the round's longest PATTERN), wtw: 32-byte units of text to fetch (uniform, 1..4)
 template <int MEASURE, int W>
 __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
-                                           const uint8_t *__restrict__ valB, uint32_t totalB, bool has, uint32_t a0,
+                                           const uint8_t *__restrict__ valB, uint32_t totalB, uint32_t firstA, uint32_t firstB, bool has, uint32_t a0,
                                            uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res WIDE_STAMP_PARAMS
                                            STRSIM_COOP_RANGES)
 {
@@ -309,11 +309,14 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     // (valA / valB and their totals are the LANE's: the symmetric measures take their text from either column, and a lane without a
     //  row reads its columns' first bytes -- the test covers every lane and its result is uniform: a cooperative fetch with some
     //  lanes switched off hands out null addresses [r4, found by tests/fuzz_gpu.py: a 32-byte literal against 33..40-byte rows])
+    // [r5] "first bytes" = the column's first byte, offsets[0] -- not values + 0: with offsets that do not start at 0 that address lies
+    // in front of the column, outside what include/strsim_amd.h lets the kernels read (found by the bounds-checked lab build on the
+    // 2^20-offset-base test; inside the caller's buffer there, but a caller is free to pass values = buffer - offsets[0]).
     const bool edge = __ballot((has && ((uint64_t)b0 + 32u * (uint32_t)W > totalB || (uint64_t)a0 + 32u * wtw > totalA)) ||
-                               totalB < 32u * (uint32_t)W || totalA < 32u * wtw) != 0ull;
+                               totalB - firstB < 32u * (uint32_t)W || totalA - firstA < 32u * wtw) != 0ull;
     if (!edge) {
         // both fetches in flight together; the pattern passes through the rows first, then the text moves in
-        const uint32_t pstart = has ? b0 : 0u, tstart = has ? a0 : 0u;
+        const uint32_t pstart = has ? b0 : firstB, tstart = has ? a0 : firstA;
         uint4 vp[CoopGeom<2 * W>::ITER];
         coop_fetch<2 * W>(valB, pstart, lane, vp STRSIM_COOP_RANGES_ARG);
         auto text = [&](auto wt) {
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
     unsigned long long wst_last = wst_t0;
 #endif
     const uint32_t totalA = offA[rowsA], totalB = offB[rowsB];
+    const uint32_t firstA = offA[0], firstB = offB[0];
 #if STRSIM_BOUNDS_ON
     ColumnRanges rg;
     rg.lo[0] = ((unsigned long long)(uintptr_t)valA + offA[0]) & ~15ull; rg.hi[0] = ((unsigned long long)(uintptr_t)valA + totalA + 15ull) & ~15ull;
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 const bool swap = la > lb; // the columns walk the shorter string
                 const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
                 const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
+                const uint32_t fT = swap ? firstB : firstA, fP = swap ? firstA : firstB; // (the columns' first bytes: offsets[0])
                 const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
                 const bool pat3 = __ballot(has && lp > 64u) != 0ull;
                 const bool pat4 = __ballot(has && lp > 96u) != 0ull;
@@ -566,11 +571,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 double res = 0.0;
                 const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
                 if (!pat3) // (the pattern is the longer string: two words or more)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                    wide_round<MEASURE, 2>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
                 else if (!pat4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                    wide_round<MEASURE, 3>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
                 else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                    wide_round<MEASURE, 4>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
                 WIDE_STAMP(3);
                 if (done) {
                     STRSIM_CHECK_INDEX(K_WIDE, 30, row, row, n);

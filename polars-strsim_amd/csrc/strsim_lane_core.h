@@ -458,6 +458,21 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
     }
 }
 
+// x / 3.0 for the sums Jaro's epilogue divides (strsim.rs:241-242), without the division: q = x * RN(1/3), one Newton correction with
+// the exact residual -- r = fma(-3, q, x); q' = fma(r, RN(1/3), q) -- which is the correctly rounded quotient (Markstein's
+// theorem: RN(1/3) is the correctly rounded reciprocal and q is within an ulp) and therefore the same double the reference's `/ 3.0`
+// produces.  Three instructions where the IEEE division sequence is about a dozen, once per row in the store phase.  Not taken on
+// faith: tests/test_lane_core_cpu.py::test_jaro_division_by_three_is_exact compares it with x / 3.0 for EVERY sum the table
+// epilogues can see (m / la + m / lb + (m - t / 2) / m, lengths up to 64: 810 160 values).  These are explicit fused
+// multiply-adds of a division algorithm, not contractions of the reference's arithmetic (-ffp-contract=off stays).
+STRSIM_HD double div3_exact(double x)
+{
+    const double y = 1.0 / 3.0; // RN(1/3) = 0x3FD5555555555555
+    const double q = x * y;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, y, q);
+}
+
 // The Jaro epilogue with its three integer quotients read from a table: q[a * QTAB_N + b] = (double)a / (double)b for
 // 0 <= a, b <= 64 (b = 0: unused), computed once with the same IEEE division -- an f64 division is ~40 VALU-equivalents
 // on CDNA.  Valid for strings of at most 32 characters.  (Measured on cfg2: Jaro +1.4 %; the single division of
@@ -466,6 +481,6 @@ constexpr int QTAB_N = 65;
 STRSIM_HD double epilogue_jaro_q(const double *q, uint32_t m, uint32_t t, uint32_t la, uint32_t lb)
 {
     if (m == 0) return 0.0;
-    return (q[m * QTAB_N + la] + q[m * QTAB_N + lb] + q[(m - t / 2) * QTAB_N + m]) / 3.0;
+    return div3_exact(q[m * QTAB_N + la] + q[m * QTAB_N + lb] + q[(m - t / 2) * QTAB_N + m]);
 }
 } // namespace strsim

@@ -235,7 +235,7 @@ __device__ __forceinline__ void stage_all_epilogues(unsigned long long pk, doubl
         return;
     }
     r[LEVENSHTEIN] = 1.0 - qd;
-    const double j = m == 0u ? 0.0 : (qa + qb + qc) / 3.0; // (strsim.rs:238-243)
+    const double j = m == 0u ? 0.0 : div3_exact(qa + qb + qc); // (strsim.rs:238-243; the division: strsim_lane_core.h)
     r[JARO] = j;
     r[JARO_WINKLER] = epilogue_jaro_winkler(j, pre);
     r[JACCARD] = epilogue_jaccard(isect, la, lb);
@@ -274,7 +274,7 @@ __device__ __forceinline__ double stage_epilogue(uint32_t pk, double qa, double 
     if (MEASURE == JARO || MEASURE == JARO_WINKLER) {
         const uint32_t m = pk & 63u, la = (pk >> 12) & 63u, lb = (pk >> 18) & 63u, pre = (pk >> 24) & 7u;
         if (la == 0u || lb == 0u) return (la == 0u && lb == 0u) ? 1.0 : 0.0;
-        const double j = m == 0u ? 0.0 : (qa + qb + qc) / 3.0;
+        const double j = m == 0u ? 0.0 : div3_exact(qa + qb + qc);
         return MEASURE == JARO_WINKLER ? epilogue_jaro_winkler(j, pre) : j;
     }
     const uint32_t isect = pk & 63u, la = (pk >> 6) & 63u, lb = (pk >> 12) & 63u;

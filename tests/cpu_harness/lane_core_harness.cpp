@@ -164,6 +164,23 @@ extern "C" int harness_check_planes(const uint8_t *bytes32)
     return 0;
 }
 
+// div3_exact (strsim_lane_core.h) against x / 3.0 over every sum Jaro's table epilogues can divide: returns the mismatches, *count = sums
+extern "C" long harness_div3_mismatches(long *count)
+{
+    long bad = 0, n = 0;
+    for (int la = 1; la <= 64; ++la)
+        for (int lb = 1; lb <= 64; ++lb)
+            for (int m = 1; m <= (la < lb ? la : lb); ++m)
+                for (int h = 0; h <= m / 2; ++h) {
+                    const double x = (double)m / (double)la + (double)m / (double)lb + (double)(m - h) / (double)m;
+                    const double a = x / 3.0, b = div3_exact(x);
+                    ++n;
+                    bad += std::memcmp(&a, &b, 8) != 0;
+                }
+    *count = n;
+    return bad;
+}
+
 // ---- wide (W-word) cores -------------------------------------------------------------------------
 struct ArrTxt { const uint32_t *w; uint32_t operator()(uint32_t g) const { return w[g]; } };
 // Jaro's string of matched characters overwrites the front of the text, as on the GPU (the text column in LDS)

@@ -36,6 +36,8 @@ def harness():
     L.harness_lane_pair_wide_tp.restype = C.c_double
     L.harness_lane_pair_wide_tp.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, C.c_int]
     L.harness_lane_pair_sym.restype = C.c_double
+    L.harness_div3_mismatches.restype = C.c_long
+    L.harness_div3_mismatches.argtypes = [C.POINTER(C.c_long)]
     L.harness_set_zip_mode.restype = None
     L.harness_set_zip_mode.argtypes = [C.c_int, C.c_uint32]
     L.harness_lane_pair_sym.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int]
@@ -395,3 +397,11 @@ def test_wide_jaro_zip_pass_over_b_or_over_the_matches(harness, measure, mode, s
                         assert bits(got) == bits(exp), (measure, W, mode, slack, a, b, got, exp)
     finally:
         harness.harness_set_zip_mode(2, 0)
+
+
+def test_jaro_division_by_three_is_exact(harness):
+    """The table epilogues of Jaro divide by 3.0 with a multiply and one exact Newton correction (div3_exact): the same double as the
+    reference's `/ 3.0` (strsim.rs:241-242) for EVERY sum they can see -- all (m, la, lb, t / 2) with lengths up to 64."""
+    n = C.c_long()
+    assert harness.harness_div3_mismatches(C.byref(n)) == 0
+    assert n.value == 810160
