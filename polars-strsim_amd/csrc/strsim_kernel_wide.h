@@ -22,7 +22,14 @@ constexpr int WIDE_WAVES = WIDE_BLOCK / 64;
 constexpr int WIDE_SPAN = STRSIM_WIDE_SPAN;  // mask words (64-row chunks) per span of k_lane_wide
 constexpr int WIDE_ROWS = WIDE_SPAN * 64;    // 4096 rows
 #ifndef STRSIM_WIDE_LIST
-#define STRSIM_WIDE_LIST 8192 // rows on k_lane_wide's sorted list (at least WIDE_ROWS): 16 KB, what the LDS of three workgroups per CU has left
+// rows on k_lane_wide's sorted list (at least WIDE_ROWS).  [r5] 4 096, where rounds 3-4 took 8 192 "because the LDS has it": a super
+// whose candidates do not fit is listed two spans (8 192 rows) at a time instead of all four, and that is FASTER wherever it happens --
+// cfg3 (5 860 candidates per super): k_lane_wide 3.76-3.94 -> 3.66-3.70 ms for Jaro-Winkler, 3.83 -> 3.43 for Levenshtein, 3.83 -> 3.21
+// for Jaccard on the same frame (profiles/r5_rounds_ab.txt) -- the rows a workgroup's rounds fetch lie within 8 192 consecutive rows
+// instead of 16 384 (two rows in most lines it touches), its collect pass is half as long a stretch without cores, and the rounds
+// lose little: 2 930 rows over 384 keys are still alike.  Lists of one span (4 096 rows: STRSIM_WIDE_SPAN=32) lose 2-3 % again; frames
+// whose supers fit (sparse wide rows) and frames of wide rows only (one span per list either way) do not change.  8 KB of LDS less.
+#define STRSIM_WIDE_LIST 4096
 #endif
 constexpr int WIDE_LIST = STRSIM_WIDE_LIST;
 static_assert(WIDE_LIST >= WIDE_ROWS && WIDE_BLOCK * 64 <= 65536, "one span always fits the list; list entries are 16-bit row indices of a super");
