@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded, strsim_codec_decode_gathered_from, STRSIM_ERR_EARLIER_CALL */
+#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded, strsim_codec_decode_gathered_from, strsim_gather_*, STRSIM_ERR_EARLIER_CALL */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -248,6 +248,27 @@ STRSIM_API uint64_t strsim_ctx_last_late_rows(strsim_ctx_t *ctx);
 /* Kernels and device copies this context has enqueued for pair calls since it was created (a call of a column whose rows
  * all fit the one-pair-per-lane kernel adds 1; a call with all kernels up front 5; introspection for tests and benches). */
 STRSIM_API uint64_t strsim_ctx_enqueued_ops(strsim_ctx_t *ctx);
+
+/* ---- the gather of the result shards over RCCL (ABI 1.5) --------------------------------------------------------------------
+ * Rows are independent, so N processes -- one per GPU -- each run strsim_pairs_device on the shard strsim_split_offsets(rows, N)
+ * gives them (the reference's own partition, strsim.rs:21-39) with no data-path collective; the one exchange step of the path is
+ * the gather of the f64 result shards onto a root rank (reference counterpart: the threads' chunks collected into one
+ * Float64Chunked, strsim.rs:98-104).  These four calls are that step for a host that binds this header (a Rust shim: INTEGRATION.md):
+ *   rank 0:      strsim_gather_unique_id(id)            -- and hands the 128 bytes to the other ranks by whatever means it has
+ *   every rank:  strsim_gather_create(ctx, id, N, rank, &g)   (collective: returns when all N ranks have called it)
+ *   every step:  strsim_gather_f64(g, shard, column, rows, root)   -- enqueued on the context's stream behind the kernels
+ * `shard`: this rank's rows of the result column (device memory, split_offsets(rows, N)[rank] of them); `column`: the whole
+ * column on the root (device memory, `rows` doubles; ignored elsewhere).  Every peer's shard travels point to point into the root
+ * (ncclSend / ncclRecv in one group: xGMI is point-to-point, seven links into the root at N = 8), the root's own shard is a device
+ * copy.  RCCL is resolved at first use (a copy the process already holds, else librccl.so.1 from the loader's path) and is not a
+ * link-time dependency of the library; without it these calls fail with STRSIM_ERR_NO_DEVICE and nothing else is affected. */
+#define STRSIM_GATHER_ID_BYTES 128
+typedef struct strsim_gather strsim_gather_t;
+STRSIM_API int strsim_gather_unique_id(uint8_t id[STRSIM_GATHER_ID_BYTES]);
+STRSIM_API int strsim_gather_create(strsim_ctx_t *ctx, const uint8_t id[STRSIM_GATHER_ID_BYTES], int world_size, int rank,
+                                    strsim_gather_t **out);
+STRSIM_API int strsim_gather_f64(strsim_gather_t *g, const double *shard, double *column, uint64_t total_rows, int root);
+STRSIM_API void strsim_gather_destroy(strsim_gather_t *g);
 
 /*
  * Lossless 16-bit transport codec for result columns (csrc/strsim_codec.hip).  A similarity of two strings of at

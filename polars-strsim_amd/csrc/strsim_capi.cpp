@@ -617,6 +617,8 @@ int strsim_ctx_synchronize(strsim_ctx_t *c)
     return rc;
 }
 
+int strsim_internal_ctx_device(strsim_ctx *c) { return c ? c->device : 0; }
+
 int strsim_internal_scan_workspace(strsim_ctx *c, uint32_t **p)
 {
     int rc = ctx_set_device(c);

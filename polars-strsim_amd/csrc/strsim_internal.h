@@ -14,3 +14,4 @@ constexpr size_t SCAN_WS_WORDS = 16384;
 
 struct strsim_ctx;
 extern "C" int strsim_internal_scan_workspace(strsim_ctx *ctx, uint32_t **p); // (hidden visibility: not exported)
+extern "C" int strsim_internal_ctx_device(strsim_ctx *ctx);                   // the HIP device ordinal of a context

@@ -133,6 +133,14 @@ def lib():
     L.strsim_ctx_last_late_rows.argtypes = [vp]
     L.strsim_codec_decode_gathered.restype = i32
     L.strsim_codec_decode_gathered.argtypes = [vp, vp, vp, u64, C.c_uint32, u64, u64, i32, u64, C.c_uint32, vp, vp]
+    L.strsim_gather_unique_id.restype = i32
+    L.strsim_gather_unique_id.argtypes = [vp]
+    L.strsim_gather_create.restype = i32
+    L.strsim_gather_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.strsim_gather_f64.restype = i32
+    L.strsim_gather_f64.argtypes = [vp, vp, vp, u64, i32]
+    L.strsim_gather_destroy.restype = None
+    L.strsim_gather_destroy.argtypes = [vp]
     L.strsim_codec_decode_gathered_from.restype = i32
     L.strsim_codec_decode_gathered_from.argtypes = [vp, vp, vp, u64, C.c_uint32, C.c_uint32, u64, u64, i32, u64, C.c_uint32, vp, vp]
     L.strsim_compact_segments.restype = i32

@@ -53,6 +53,48 @@ def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=
     return finish()
 
 
+class AbiGather:
+    """The C ABI's own gather (include/strsim_amd.h: strsim_gather_*): RCCL point-to-point sends of the ragged f64 shards into the
+    root, enqueued on the context's stream -- what a host that binds the header (and has no torch.distributed) uses.  The 128-byte
+    unique id of rank 0 has to reach every rank by the host's own means (a file, MPI, a socket; `unique_id()` makes it)."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from ._lib import check, lib
+        buf = (C.c_uint8 * AbiGather.ID_BYTES)()
+        check(lib().strsim_gather_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, uid, world_size, rank):
+        import ctypes as C
+        from ._lib import check, lib
+        self.ctx, self.world, self.rank = ctx, int(world_size), int(rank)
+        self._h = C.c_void_p()
+        ub = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(bytes(uid))
+        check(lib().strsim_gather_create(ctx._h, ub, self.world, self.rank, C.byref(self._h)))
+
+    def gather(self, shard, column, total_rows, root=0):
+        """shard: this rank's f64 rows (torch CUDA tensor, split_offsets(total_rows, world)[rank] of them); column: the root's
+        [total_rows] f64 tensor (None elsewhere).  Asynchronous on the context's stream."""
+        from ._lib import check, lib
+        check(lib().strsim_gather_f64(self._h, shard.data_ptr() if shard is not None and shard.numel() else None,
+                                      column.data_ptr() if column is not None else None, int(total_rows), int(root)))
+
+    def close(self):
+        from ._lib import lib
+        if getattr(self, "_h", None) and self._h.value:
+            lib().strsim_gather_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardGatherer:
     """Ships every step's result shard(s) to rank 0 on a side stream, overlapped with the next step's kernels.
 

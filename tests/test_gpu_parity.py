@@ -994,3 +994,31 @@ def test_column_from_views_malformed_slots_cannot_fault(S, ctx):
     ctx.synchronize()
     assert int(bad.item()) == 3 + 3000 and bytes(val.cpu().numpy()[:3]) == b"abc"
     assert not val.cpu().numpy()[3:].any()  # nothing else was written
+
+
+def test_c_abi_gather_single_rank(S, ctx):
+    """strsim_gather_* (ABI 1.5): RCCL resolved at first use (no link-time dependency), a communicator of ONE rank on this GPU, the
+    gather of its shard into the column on the context's stream -- the root's own shard is a device copy; more ranks need more GPUs
+    (RCCL refuses two ranks on one device) and run only on a node.  Argument errors are reported, not crashed on."""
+    import torch
+    from strsim_amd.distributed import AbiGather
+    dev = torch.device("cuda", 0)
+    uid = AbiGather.unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = AbiGather(ctx, uid, 1, 0)
+    n = 100_003
+    oa, va = S.pack_strings(["phillips"] * n)
+    ob, vb = S.pack_strings(["philips"] * n)
+    t = lambda x, dt: torch.from_numpy(x.view(dt)).to(dev)
+    pad = np.zeros(64, dtype=np.uint8)
+    shard = ctx.pairs_device("jaro_winkler", t(oa, np.int32), t(np.concatenate([va, pad]), np.uint8), t(ob, np.int32),
+                             t(np.concatenate([vb, pad]), np.uint8))
+    column = torch.zeros(n, dtype=torch.float64, device=dev)
+    g.gather(shard, column, n, root=0)   # behind the kernels, in stream order
+    ctx.synchronize()
+    assert bool((column == 0.975).all()) and torch.equal(column.view(torch.int64), shard.view(torch.int64))
+    with pytest.raises(S.StrsimError):
+        g.gather(shard, column, n, root=3)
+    with pytest.raises(S.StrsimError):
+        AbiGather(ctx, uid, 2, 5)
+    g.close()
