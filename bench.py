@@ -307,21 +307,33 @@ def main():
         torch.cuda.synchronize()
 
     # One-launch calls stay pending until they are retired, and the context's ring holds 32 of them: a caller that never retires
-    # makes strsim_pairs_device synchronise the stream at every wrap -- inside the timed loop.  So the loop keeps a window of
-    # INFLIGHT steps: before step i is enqueued, step i - INFLIGHT (complete by its own event) is retired call by call.
-    INFLIGHT = 8
+    # makes strsim_pairs_device synchronise the stream at every wrap -- inside the timed loop.  So the loop keeps a WINDOW: calls are
+    # retired in batches of about eight (one event per batch, recorded behind its last step), the oldest batch -- complete by its
+    # event -- whenever another batch would take the calls in flight past 24.
     calls_per_step = len(parts) * (1 if fused else len(measures))
-    window = [torch.cuda.Event() for _ in range(INFLIGHT)] if not gather else None
+    batch_steps = max(1, 8 // calls_per_step)
+    INFLIGHT_CALLS = max(24, 2 * calls_per_step * batch_steps)  # (< 32 for every config of BASELINE.json)
+    windowed = not gather
 
     def run(nsteps):
+        batches = []  # (event behind the batch's last step, calls in the batch), oldest first
+        pending = in_batch = 0
         for i in range(nsteps):
-            if window is not None and i >= INFLIGHT:
-                window[i % INFLIGHT].synchronize()
-                for _ in range(calls_per_step):
+            if windowed and in_batch == 0 and batches and pending + calls_per_step * batch_steps > INFLIGHT_CALLS:
+                ev, ncalls = batches.pop(0)
+                ev.synchronize()
+                for _ in range(ncalls):
                     ctx.retire_oldest()
+                pending -= ncalls
             step(i)
-            if window is not None:
-                window[i % INFLIGHT].record(compute_stream)
+            if windowed:
+                in_batch += 1
+                if in_batch == batch_steps or i == nsteps - 1:
+                    ev = torch.cuda.Event()
+                    ev.record(compute_stream)
+                    batches.append((ev, in_batch * calls_per_step))
+                    pending += in_batch * calls_per_step
+                    in_batch = 0
         drain()
 
     # Preheat (disclosed in the JSON line): the first 25-40 ms after the GPU goes from idle to this load run ~5-10 % slower
@@ -439,7 +451,7 @@ def main():
                        # a call is its first kernel alone unless the context's last call left slow rows) when nothing is gathered,
                        # the default stream-ordered mode (every kernel of the chain up front) under the gather
                        "call_mode": "stream_ordered (ABI default)" if gather else "one_launch (opt-in, strsim_ctx_set_stream_ordered(ctx, 0))",
-                       "calls_in_flight_max": None if gather else INFLIGHT * calls_per_step,
+                       "calls_in_flight_max": None if gather else INFLIGHT_CALLS,
                        "partition": "split_offsets(rows, N) (strsim.rs:21-39)" if (world == 1 or a.root_share == 1.0 or a.scaling == "weak")
                                     else "DEVIATION --root-share %g: rank 0 holds %d rows, the others split the rest by split_offsets" % (a.root_share, rows),
                        "distributed": distributed,

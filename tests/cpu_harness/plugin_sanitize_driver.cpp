@@ -26,6 +26,7 @@ int _strsim_test_pack_series(SeriesExport *series, uint64_t r0, uint64_t r1, uin
                              uint64_t *rows_out, uint64_t *bytes_out, uint8_t *valid_out, unsigned threads);
 int _strsim_test_pack_onepass(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t bpr256, unsigned threads, uint8_t *val_out,
                               uint64_t val_cap, uint8_t *len_out, uint64_t *bytes_out, int *nseg_out);
+int _strsim_test_pack_grants(int engine_parallel, int n_calls, uint64_t rows, unsigned *threads_out, int *helpers_out);
 int _strsim_test_validity(SeriesExport *two_series, uint64_t *words, int64_t *null_count, double *vals, uint64_t *rows_out,
                           unsigned threads);
 int _strsim_test_pack_views(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t lbpr256, unsigned threads, uint8_t *views_out,
@@ -297,6 +298,16 @@ void one_round(unsigned seed)
         CHECK(nulls == want_nulls, "null count %lld / %lld", (long long)nulls, (long long)want_nulls);
         CHECK(two[0].release == nullptr && two[1].release == nullptr, "the inputs were not released");
     }
+    // ---- (4) the helper-thread budget of engine-parallel calls, borrowed and returned by several caller threads at once: what is
+    //      lent out at any moment never exceeds half the CPUs (the grant of every call in flight, other threads' included)
+    {
+        unsigned t3[3] = {0, 0, 0};
+        int lent = -1;
+        (void)_strsim_test_pack_grants(1, 3, 10000000ull, t3, &lent);
+        const int budget = (int)(std::thread::hardware_concurrency() < 32u ? std::thread::hardware_concurrency() : 32u) / 2;
+        CHECK(lent >= 0 && lent <= budget, "helpers lent out: %d of a budget of at most %d", lent, budget);
+        CHECK(t3[0] >= 1 && t3[1] >= 1 && t3[2] >= 1, "a call packs on at least its own thread");
+    }
 }
 
 } // namespace
@@ -308,6 +319,11 @@ int main(int argc, char **argv)
     for (int t = 0; t < callers; ++t)
         th.emplace_back([=] { for (int r = 0; r < rounds; ++r) one_round((unsigned)(t * 1000 + r)); });
     for (auto &x : th) x.join();
+    {   // every permit came back
+        unsigned t1[1];
+        int lent = 0;
+        if (_strsim_test_pack_grants(1, 0, 0, t1, &lent) != 0) { fprintf(stderr, "CHECK FAILED: helper permits were not returned\n"); ++g_failures; }
+    }
     printf("plugin_sanitize_driver: %d caller threads x %d rounds, %ld chunk releases, %ld series releases, %ld check failures\n", callers,
            rounds, (long)g_array_releases, (long)g_series_releases, (long)g_failures);
     return g_failures ? 1 : 0;
