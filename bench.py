@@ -210,13 +210,11 @@ def main():
         shards = [(r * (total_rows // world), total_rows // world) for r in range(world)]
     else:
         total_rows = a.rows or cfg[1]
-        shards = S.split_offsets(total_rows, world)  # strsim.rs:21-39
-        if world > 1 and a.root_share != 1.0:
-            if not 0.0 <= a.root_share <= 1.0:
-                raise SystemExit("--root-share is a fraction of an equal share: 0 .. 1")
-            r0 = int(total_rows // world * a.root_share) // 64 * 64
-            rest = S.split_offsets(total_rows - r0, world - 1)  # the reference's rule over the remaining ranks
-            shards = [(0, r0)] + [(r0 + o, ln) for o, ln in rest]
+        from strsim_amd.distributed import shard_ranges
+        try:
+            shards = shard_ranges(total_rows, world, a.root_share)  # strsim.rs:21-39 (root_share 1.0: exactly)
+        except ValueError as e:
+            raise SystemExit("--root-share: %s" % e)
     row_base, rows = shards[rank]
 
     # a shard whose packed values would not fit 32-bit offsets (cfg5: ~5 GB per column) is held as several row batches,

@@ -18,6 +18,20 @@ def shard_range(n_rows, world_size, rank):
     return split_offsets(n_rows, world_size)[rank]
 
 
+def shard_ranges(n_rows, world_size, root_share=1.0):
+    """[(offset, len)] * world_size.  root_share == 1: the reference's partition, split_offsets(n_rows, world_size) (strsim.rs:21-39).
+    Otherwise a DEVIATION for a root that also decodes the gathered column: rank 0 holds root_share of an
+    equal share, in whole 64-row chunks, and the other ranks split the rest by the reference's rule."""
+    parts = split_offsets(n_rows, world_size)
+    if world_size <= 1 or root_share == 1.0:
+        return parts
+    if not 0.0 <= root_share <= 1.0:
+        raise ValueError("root_share is a fraction of an equal share: 0 .. 1")
+    r0 = int(n_rows // world_size * root_share) // 64 * 64
+    rest = split_offsets(n_rows - r0, world_size - 1)
+    return [(0, r0)] + [(r0 + o, ln) for o, ln in rest]
+
+
 def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=None):
     """Gather the per-rank result shards (1-D tensors laid out by shard_range) onto `dst`.
 

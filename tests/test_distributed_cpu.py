@@ -74,3 +74,28 @@ def test_shard_ranges_cover_rows():
         assert parts[0][0] == 0 and sum(p[1] for p in parts) == n
         for a, b in zip(parts, parts[1:]):
             assert a[0] + a[1] == b[0] or a[1] == 0
+
+
+def test_shard_ranges_reference_rule_and_the_root_share_deviation():
+    """shard_ranges: split_offsets(rows, N) by default (strsim.rs:21-39: rows / N each, the remainder to the last rank); with
+    root_share < 1 rank 0 holds that fraction of an equal share in whole 64-row chunks and the others split the rest by the same rule --
+    contiguous, complete, in order."""
+    for p in (os.path.join(ROOT, "polars-strsim_amd"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from strsim_amd.distributed import shard_ranges
+    import oracle_lib as O
+    for n, w in ((100_000_000, 8), (1_000_001, 2), (7, 8), (0, 3), (12345, 1)):
+        assert shard_ranges(n, w) == O.split_offsets(n, w)
+    for n, w, share in ((100_000_000, 8, 0.4), (1_000_000, 2, 0.5), (1_000_001, 3, 0.0), (999, 4, 0.9)):
+        parts = shard_ranges(n, w, share)
+        assert len(parts) == w and parts[0][0] == 0 and parts[0][1] % 64 == 0 and parts[0][1] <= n // w
+        assert abs(parts[0][1] - n // w * share) < 64
+        at = 0
+        for off, ln in parts:
+            assert off == at
+            at += ln
+        assert at == n
+        assert [ln for _o, ln in parts[1:]] == [ln for _o, ln in O.split_offsets(n - parts[0][1], w - 1)]
+    with pytest.raises(ValueError):
+        shard_ranges(100, 2, 1.5)
