@@ -779,12 +779,15 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
 
 // workgroups per CU (= waves per SIMD): 5 by LDS (28 KB) and registers (<= 96) without match-mask tables, 4 with them (40 KB;
 // Jaro's two passes want the registers anyway), 3 for the five-output pass (three cores' state at once)
+#ifndef STRSIM_STAGE_PLAIN_WAVES
+#define STRSIM_STAGE_PLAIN_WAVES 5 // workgroups per CU of the instantiations without tables (6 needs <= 26.6 KB of LDS and 80 registers: measured)
+#endif
 #ifndef STRSIM_STAGE_ALL_WAVES_PER_EU
 #define STRSIM_STAGE_ALL_WAVES_PER_EU 3
 #endif
 template <int MEASURE, bool TABLES, bool LONG = false> constexpr int stage_waves_per_eu()
 {
-    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : ((TABLES || LONG) ? 4 : 5);
+    constexpr int lim = MEASURE == ALL_MEASURES ? STRSIM_STAGE_ALL_WAVES_PER_EU : ((TABLES || LONG) ? 4 : STRSIM_STAGE_PLAIN_WAVES);
     return STRSIM_STAGE_WAVES_PER_EU < lim ? STRSIM_STAGE_WAVES_PER_EU : lim;
 }
 
