@@ -45,6 +45,15 @@ def parse():
     p.add_argument("--measure", default="", help="override the config's measure")
     p.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the result shards")
     p.add_argument("--no-codec", action="store_true", help="N>1: gather raw f64 instead of 16-bit codes")
+    p.add_argument("--gather", default="auto", choices=["auto", "abi", "torch"],
+                   help="N>1, which gather carries the result shards: abi = the C ABI's own (strsim_gather_f64_ranges: grouped RCCL send/recv "
+                        "of the raw f64 shards, north_star's literal form; implies --no-codec), torch = torch.distributed.gather (coded "
+                        "when the strings allow).  auto: abi when the column travels as f64 anyway (--no-codec, cfg3, cfg5), else torch")
+    p.add_argument("--no-abi-leg", action="store_true",
+                   help="N>1: skip the second, separately reported leg that repeats the steps with the C ABI's f64 gather when the "
+                        "headline used torch.distributed's (config.abi_gather_leg)")
+    p.add_argument("--abi-leg-timeout", type=float, default=120.0, help="seconds before the C-ABI-gather leg is given up (the headline line is printed regardless)")
+    p.add_argument("--no-extra-modes", action="store_true", help="skip value_default_mode and cold_first_call_ms (extra fields)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the control flow)")
     p.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -243,19 +252,40 @@ def main():
     ctx.set_stream_ordered(bool(gather))
     shipper = None
     gather_note = None
+    codec_chars = 32 if ((hi <= 32 or a.force_codec) and not a.no_codec and a.gather != "abi") else None
+    rccl_reachable = a.backend == "nccl" or bool(os.environ.get("STRSIM_RCCL_LIB"))  # (real RCCL refuses two ranks on one GPU)
+    impl = a.gather if a.gather != "auto" else ("abi" if codec_chars is None and rccl_reachable else "torch")
+
+    def agree(ok):  # every rank takes the same decision: MIN over the ranks' flags (a collective every rank reaches)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def abi_gather_available():
+        """Non-collective: can this rank load an RCCL and make a unique id?  Agreed on before any rank enters ncclCommInitRank."""
+        from strsim_amd.distributed import AbiGather
+        try:
+            AbiGather.unique_id()
+            return True, None
+        except Exception as e:
+            return False, repr(e)[:300]
+
     if gather:
         from strsim_amd.distributed import ShardGatherer, gather_column
-        def agree(ok):  # every rank takes the same decision: MIN over the ranks' flags (a collective every rank reaches)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return int(flag.item()) == 1
+        # (0) the C ABI's gather builds its communicator inside the constructor (collective): make sure every rank can get there
+        if impl == "abi":
+            ok, why = abi_gather_available()
+            if not agree(ok):
+                gather_note = "--gather abi fell back to torch.distributed.gather: " + (why or "RCCL is not loadable on another rank")
+                impl = "torch"
+                codec_chars = 32 if ((hi <= 32 or a.force_codec) and not a.no_codec) else None
         # (1) the fallible NON-collective setup first, agreed on before any rank enters a gather: a rank that failed here must
         #     not skip a collective the others are already inside (mismatched collectives hang on RCCL)
         ok = 1
         try:
             # strings of at most 32 characters take < 2^16 distinct similarity values: ship 16-bit codes, decode on rank 0
             shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend, parts=shards,
-                                    codec_chars=32 if ((hi <= 32 or a.force_codec) and not a.no_codec) else None)
+                                    codec_chars=codec_chars, impl=impl)
             probe = torch.zeros(64, dtype=torch.uint8, device="cpu" if shipper.host else dev)
         except Exception as e:  # reported in the JSON line (gather_f64_to_rank0 false + gather_note), never silent
             ok = 0
@@ -280,6 +310,7 @@ def main():
                 gather_note = gather_note or "gather disabled: the preflight failed on another rank"
         if not gather:
             print(f"[bench rank {rank}] {gather_note}", file=sys.stderr)
+            ctx.set_stream_ordered(False)  # (ShardGatherer had put the context into stream-ordered mode: nothing reads behind an event now)
     fused = len(measures) == 5  # cfg4: strsim_pairs_device_all, one fused pass with five outputs
 
     def step(i):
@@ -337,6 +368,22 @@ def main():
     # Preheat (disclosed in the JSON line): the first 25-40 ms after the GPU goes from idle to this load run ~5-10 % slower
     # (clock ramp), which a short run (--warmup 5 --steps 20 is 35 ms) would measure instead of the steady state a 100 M-row
     # job is in.  One step is timed to size the preheat; every rank runs the same number of steps (the gather is collective).
+    # What ONE call costs a caller who does not loop: the very first call of the context -- workspace
+    # allocation, code-object load, idle clocks -- and a call on a GPU that has been idle for a second with everything warm.
+    # Wall clock around step + drain on this rank (at N > 1 the step includes its gather).  Untimed as far as `value` goes.
+    cold_first_call_ms = idle_gpu_call_ms = None
+    if not a.no_extra_modes:
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        step(0)
+        drain()
+        cold_first_call_ms = (time.perf_counter() - t0) * 1e3
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        step(1)
+        drain()
+        idle_gpu_call_ms = (time.perf_counter() - t0) * 1e3
     preheat_steps = 0
     if a.preheat_ms > 0:
         step(0)
@@ -384,23 +431,52 @@ def main():
                      "shipment_ms_per_column": None if float(v[2].item()) < 0 else round(float(v[2].item()), 4),
                      "wall_ms_per_step": round(float(v[3].item()), 4)} for r, v in enumerate(all_)]
 
-    gather_ok = None
-    if world > 1:
-        cdev = dev if a.backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if gather:
-            # outside the timed region: what rank 0 holds for the last shipped column must equal every rank's shard
-            last = out[((a.steps - 1) & 1) * len(measures) + len(measures) - 1]
-            mine = last.view(torch.int64).sum().reshape(1).to(cdev)
-            sums = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(sums, mine)
-            if rank == 0:
-                got = shipper.result()
-                gather_ok = all(int(got[o:o + ln].view(torch.int64).sum().item()) == int(sums[r].item())
-                                for r, (o, ln) in enumerate(shards))
+        return float(t.item())
 
+    def verify_gather(sh, nsteps):
+        """Outside any timed region: what rank 0 holds for the last shipped column must equal every rank's shard (64-bit sums of the
+        bit patterns, shard by shard).  Collective; the verdict on rank 0, None elsewhere."""
+        cdev = dev if a.backend == "nccl" else "cpu"
+        last = out[((nsteps - 1) & 1) * len(measures) + len(measures) - 1]
+        mine = last.view(torch.int64).sum().reshape(1).to(cdev)
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        if rank != 0:
+            return None
+        got = sh.result()
+        return all(int(got[o:o + ln].view(torch.int64).sum().item()) == int(sums[r].item()) for r, (o, ln) in enumerate(shards))
+
+    dt = max_over_ranks(dt)
+    gather_ok = verify_gather(shipper, a.steps) if (world > 1 and gather) else None
+    call_mode_timed = "stream_ordered (ABI default)" if ctx.stream_ordered else "one_launch (opt-in, strsim_ctx_set_stream_ordered(ctx, 0))"
+    gather_impl = None if not gather else ("abi: strsim_gather_f64_ranges (grouped RCCL send/recv into the root's column)" if shipper.impl == "abi"
+                                           else "torch.distributed.gather (shards padded to the longest)")
+    rccl_comm_ranks = shipper.comm_ranks() if gather else None
+
+    # The same steps in the ABI's DEFAULT mode (every kernel of the chain up front: what a caller who never opts in gets), timed the
+    # same way right after the headline -- an extra field, never `value` (VERDICT r5, weak 8).  N = 1 only: under a gather the
+    # headline already runs in that mode.
+    default_mode = None
+    if world == 1 and not a.no_extra_modes and not ctx.stream_ordered:
+        ctx.set_stream_ordered(True)
+        run(min(a.warmup, 5))
+        torch.cuda.synchronize()
+        ops0 = ctx.enqueued_ops
+        t0 = time.perf_counter()
+        run(a.steps)
+        torch.cuda.synchronize()
+        dt_d = time.perf_counter() - t0
+        default_mode = {"value": total_rows * a.steps / dt_d / 1e6, "ms_per_step": dt_d / a.steps * 1e3,
+                        "enqueued_kernels_and_copies_per_step": (ctx.enqueued_ops - ops0) / max(a.steps, 1),
+                        "call_mode": "stream_ordered (ABI default)", "steps": a.steps, "warmup": min(a.warmup, 5)}
+        ctx.set_stream_ordered(False)
+
+    res = None
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = total_rows * a.steps / dt / 1e6
@@ -412,7 +488,7 @@ def main():
         wave_ms = tm["wave_ms"] / max(tm["wave_launches"], 1) * nparts
         # HBM traffic of the dominant kernel from a separate rocprofv3 --pmc run of this same command
         # (bench_support/profile.sh -> profiles/traffic.json; FETCH_SIZE doubled per the gfx950 note)
-        traffic = None
+        traffic, traffic_source = None, "none (no counter run of this library build and workload in profiles/traffic.json)"
         try:
             import hashlib
             from strsim_amd import _lib as L_
@@ -422,6 +498,7 @@ def main():
             # only a counter run of THIS build counts (bench_support/profile.sh records the library's hash with the figure)
             if len(measures) == 1 and key in tj and tj[key].get("lib_sha256") == lib_sha:
                 traffic = tj[key]["traffic_bytes_per_launch"] * nparts  # per pass over the whole shard, like `achieved`
+                traffic_source = "replayed: profiles/traffic.json[%s]@lib sha256 %s (rocprofv3 --pmc passes of bench_support/profile.sh)" % (key, lib_sha)
         except Exception:
             pass
         # the dominant kernel: k_lane_stage, unless the slow-row chain after it (k_lane_wide / k_lane_utf8 /
@@ -448,11 +525,11 @@ def main():
                        # how the calls were enqueued: one-launch calls (strsim_ctx_set_stream_ordered(ctx, 0), the ABI's opt-in mode:
                        # a call is its first kernel alone unless the context's last call left slow rows) when nothing is gathered,
                        # the default stream-ordered mode (every kernel of the chain up front) under the gather
-                       "call_mode": "stream_ordered (ABI default)" if gather else "one_launch (opt-in, strsim_ctx_set_stream_ordered(ctx, 0))",
-                       "calls_in_flight_max": None if gather else INFLIGHT_CALLS,
+                       "call_mode": call_mode_timed,  # (read from the context: strsim_ctx_get_stream_ordered)
+                       "calls_in_flight_max": INFLIGHT_CALLS if windowed else None,
                        "partition": "split_offsets(rows, N) (strsim.rs:21-39)" if (world == 1 or a.root_share == 1.0 or a.scaling == "weak")
                                     else "DEVIATION --root-share %g: rank 0 holds %d rows, the others split the rest by split_offsets" % (a.root_share, rows),
-                       "distributed": distributed,
+                       "distributed": dict(distributed, gather_impl=gather_impl, rccl_comm_ranks=rccl_comm_ranks),
                        "gather_f64_to_rank0": bool(gather),
                        "gather_transport": shipper.transport if shipper else None,
                        "codec_exceptions": shipper.exceptions() if shipper else None,
@@ -461,10 +538,18 @@ def main():
                        "per_rank": per_rank, "root_decode_ms_per_column": None if decode_ms is None else round(decode_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # `traffic` is never measured inside this run (PMC counters need their own rocprofv3 passes): it is the
+                         # figure bench_support/profile.sh recorded for THIS library build and THIS workload, or nothing
+                         "traffic_source": traffic_source,
                          "algorithmic_read_bytes": read_bytes, "algorithmic_write_bytes": write_bytes,
                          "kernel_ms": lane_ms, "wave_kernel_ms": wave_ms,
                          "achieved_read_plus_write": (read_bytes + write_bytes) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
         }
+        res["value_default_mode"] = None if default_mode is None else round(default_mode["value"], 3)
+        res["default_mode"] = default_mode if default_mode is not None else (
+            "the headline ran in the default mode" if ctx.stream_ordered or gather else None)
+        res["cold_first_call_ms"] = None if cold_first_call_ms is None else round(cold_first_call_ms, 3)
+        res["idle_gpu_call_ms"] = None if idle_gpu_call_ms is None else round(idle_gpu_call_ms, 3)
         if a.config == "cfg5" or hi > 128:
             cells = 0.0
             for _r0, _r1, oa, _va, ob, _vb in parts:
@@ -485,8 +570,67 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
                 res["cpu_baseline"] = {"value": None, "unit": "M string-pairs/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    # N > 1, headline gathered by torch.distributed (coded): the same steps once more with the C ABI's OWN gather (raw f64 over grouped
+    # RCCL send/recv, north_star's literal form), reported beside the headline as config.abi_gather_leg -- so that the driver's
+    # default scaling run is also the first contact of strsim_gather_* with real RCCL ranks.  Guarded: the headline
+    # line is complete before the leg starts, and a leg that hangs (a collective some rank never reaches) is given up by a timer that
+    # prints the line as it stands and leaves.
+    leg_failed = False
+    if world > 1 and gather and shipper.impl == "torch" and not a.no_abi_leg and rccl_reachable:
+        import threading
+        leg, lock, done = {"ok": False, "stage": "availability"}, threading.Lock(), [False]
+
+        def give_up():
+            with lock:
+                if done[0]:
+                    return
+                if rank == 0:
+                    res["config"]["abi_gather_leg"] = dict(leg, ok=False, error="given up after %g s (--abi-leg-timeout) in stage '%s'" % (a.abi_leg_timeout, leg["stage"]))
+                    print(json.dumps(res), flush=True)
+                if rank != 0:
+                    time.sleep(3.0)  # (rank 0's line first: a launcher that sees a rank leave may end the others)
+                os._exit(0)
+
+        timer = threading.Timer(a.abi_leg_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            ok, why = abi_gather_available()
+            if not agree(ok):
+                leg["error"] = why or "RCCL is not loadable on another rank"
+            else:
+                leg["stage"] = "communicator (ncclCommInitRank)"
+                headline_shipper = shipper
+                shipper = ShardGatherer(ctx, compute_stream, measures, rows, dev, backend=a.backend, parts=shards, codec_chars=None, impl="abi")
+                leg["stage"] = "steps"
+                run(min(a.warmup, 5))
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(a.steps)
+                dist.barrier()
+                torch.cuda.synchronize()
+                dt_l = max_over_ranks(time.perf_counter() - t0)
+                leg["stage"] = "verification"
+                ok_l = verify_gather(shipper, a.steps)
+                leg.update(ok=True, stage="done", value=total_rows * a.steps / dt_l / 1e6, unit="M string-pairs/s", ms_per_step=dt_l / a.steps * 1e3,
+                           steps=a.steps, warmup=min(a.warmup, 5), gather_impl="abi: strsim_gather_f64_ranges", transport=shipper.transport,
+                           rccl_comm_ranks=shipper.comm_ranks(), gather_verified=ok_l)
+                shipper.close()
+                shipper = headline_shipper
+        except Exception as e:
+            leg["error"] = repr(e)[:300]
+        with lock:
+            done[0] = True
+        timer.cancel()
+        leg_failed = not leg["ok"]
+        if rank == 0:
+            res["config"]["abi_gather_leg"] = leg
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        if leg_failed:  # ranks may have left the leg at different collectives: do not wait for one another
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -98,6 +98,15 @@ POLARS_PLUGIN_DECLARE(jaro_winkler)
 POLARS_PLUGIN_DECLARE(jaccard)
 POLARS_PLUGIN_DECLARE(sorensen_dice)
 
+/* ---- diagnostics of this implementation (not part of the polars-ffi contract; the engine never calls them) ----
+ * The plugin's staging -- pinned host memory and its device mirrors, per pipeline set -- is leased per call from one process-wide
+ * pool under POLARS_STRSIM_STAGING_BUDGET_MB (csrc/plugin_pack.h: StagingPool; reference counterpart: the per-call scratch of
+ * strsim.rs:78-84, :109-123).  out[0..7] = live pinned bytes, live device bytes, budget bytes (0 = none), pipeline sets, sets in use,
+ * sets released so far, calls that had to wait for the budget, peak live bytes seen when a call returned. */
+POLARS_PLUGIN_API void _polars_plugin_strsim_staging_stats(uint64_t out[8]);
+/* Change the budget of a running process (tests; 0 = no budget).  Takes effect with the next call. */
+POLARS_PLUGIN_API void _polars_plugin_strsim_staging_set_budget_mb(uint64_t megabytes);
+
 #ifdef __cplusplus
 }
 #endif

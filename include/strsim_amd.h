@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRSIM_ABI_VERSION 0x00010005u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded, strsim_codec_decode_gathered_from, strsim_gather_*, STRSIM_ERR_EARLIER_CALL */
+#define STRSIM_ABI_VERSION 0x00010006u /* major<<16 | minor; 1.1: strsim_pairs_device_small, strsim_codec_patch_indirect; 1.2: strsim_ctx_retire_oldest, strsim_offsets_from_lengths; 1.3: one-launch calls (strsim_ctx_set_stream_ordered, strsim_ctx_last_late_rows); 1.4: one-launch calls are OPT-IN -- a new context completes rows in stream order, as in 1.2; 1.5: strsim_column_from_views_bounded, strsim_codec_decode_gathered_from, strsim_gather_*, STRSIM_ERR_EARLIER_CALL; 1.6: strsim_gather_f64_ranges, strsim_gather_comm_count, strsim_ctx_get_stream_ordered */
 
 #if defined(__GNUC__)
 #define STRSIM_API __attribute__((visibility("default")))
@@ -152,6 +152,8 @@ STRSIM_API int strsim_ctx_synchronize(strsim_ctx_t *ctx);
  * order); 0: calls that are expected to need the first kernel only are one launch (see strsim_pairs_device).  Takes effect
  * with the next call; calls already pending keep the mode they were enqueued in. */
 STRSIM_API int strsim_ctx_set_stream_ordered(strsim_ctx_t *ctx, int enable);
+/* The mode the NEXT call of the context is enqueued in: 1 = stream-ordered (the default), 0 = one-launch calls (ABI 1.6). */
+STRSIM_API int strsim_ctx_get_stream_ordered(strsim_ctx_t *ctx);
 
 /*
  * Same contract with HOST-RESIDENT buffers: stages the shards to the device, runs the kernels and
@@ -261,13 +263,21 @@ STRSIM_API uint64_t strsim_ctx_enqueued_ops(strsim_ctx_t *ctx);
  * column on the root (device memory, `rows` doubles; ignored elsewhere).  Every peer's shard travels point to point into the root
  * (ncclSend / ncclRecv in one group: xGMI is point-to-point, seven links into the root at N = 8), the root's own shard is a device
  * copy.  RCCL is resolved at first use (a copy the process already holds, else librccl.so.1 from the loader's path) and is not a
- * link-time dependency of the library; without it these calls fail with STRSIM_ERR_NO_DEVICE and nothing else is affected. */
+ * link-time dependency of the library; without it these calls fail with STRSIM_ERR_NO_DEVICE and nothing else is affected.
+ * STRSIM_RCCL_LIB=<path> names the library to use instead (read once per process). */
 #define STRSIM_GATHER_ID_BYTES 128
 typedef struct strsim_gather strsim_gather_t;
 STRSIM_API int strsim_gather_unique_id(uint8_t id[STRSIM_GATHER_ID_BYTES]);
 STRSIM_API int strsim_gather_create(strsim_ctx_t *ctx, const uint8_t id[STRSIM_GATHER_ID_BYTES], int world_size, int rank,
                                     strsim_gather_t **out);
 STRSIM_API int strsim_gather_f64(strsim_gather_t *g, const double *shard, double *column, uint64_t total_rows, int root);
+/* The same over an explicit partition (ABI 1.6): ranges = uint64[2 * N], rank r holds rows [ranges[2r], ranges[2r] + ranges[2r+1])
+ * of the column -- for a host whose shards are not split_offsets' (a root that takes a smaller share because it also assembles the
+ * column: a named deviation from strsim.rs:21-39).  The same array on every rank; overlapping ranges are refused. */
+STRSIM_API int strsim_gather_f64_ranges(strsim_gather_t *g, const double *shard, double *column, const uint64_t *ranges, int root);
+/* How many ranks the RCCL communicator of `g` itself holds (ncclCommCount): the answer to "did RCCL form the world I think it did"
+ * that does not go through the caller's own bookkeeping (ABI 1.6). */
+STRSIM_API int strsim_gather_comm_count(strsim_gather_t *g, int *count);
 STRSIM_API void strsim_gather_destroy(strsim_gather_t *g);
 
 /*

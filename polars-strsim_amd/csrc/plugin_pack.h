@@ -1,7 +1,7 @@
 // plugin_pack.h -- the host's packing machinery: the per-thread fork-join pool, pinned staging slots and device pipelines, the device list,
 // the CPU quota and the helper-thread budget of engine-parallel calls, and the slice packers that fill a slot.
-// Included by polars_plugin.cpp inside its anonymous namespace, in this order ([r5] split out of polars_plugin.cpp along its seams,
-// no behaviour change -- the object code is identical before and after).
+// Included by polars_plugin.cpp inside its anonymous namespace, in this order ([r5] split out of polars_plugin.cpp along its seams).
+// [r6] the pipelines are leased per call from one process-wide pool under a staging budget (StagingPool) instead of living with the thread.
 // Reference: parallel_apply, /root/reference/src/expressions/strsim.rs:41-107.
 #pragma once
 
@@ -119,7 +119,10 @@ void fork_join(unsigned nthreads, const std::function<void(unsigned)> &fn) { g_p
         if (e__ != hipSuccess) fail(std::string("HIP error in " #expr ": ") + hipGetErrorString(e__)); \
     } while (0)
 
-// grow-only buffer: pinned host memory or device memory
+// staging memory alive in this process right now, over every pipeline set (polars_strsim_staging_stats reports them)
+std::atomic<uint64_t> g_live_pinned{0}, g_live_device{0};
+
+// grow-only buffer: pinned host memory or device memory (given back as a whole when its pipeline set is released: StagingPool)
 struct Buf {
     void *p = nullptr;
     size_t cap = 0;
@@ -131,10 +134,14 @@ struct Buf {
         const size_t want = bytes + bytes / 4 + 4096;
         if (device) HIP_OR_FAIL(hipMalloc(&p, want)); else HIP_OR_FAIL(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
+        (device ? g_live_device : g_live_pinned).fetch_add(want, std::memory_order_relaxed);
     }
     void release()
     {
-        if (p) { if (device) (void)hipFree(p); else (void)hipHostFree(p); }
+        if (p) {
+            if (device) (void)hipFree(p); else (void)hipHostFree(p);
+            (device ? g_live_device : g_live_pinned).fetch_sub(cap, std::memory_order_relaxed);
+        }
         p = nullptr; cap = 0;
     }
 };
@@ -153,9 +160,18 @@ struct Slot {
     // view-native slices (pack_slice_views): the views as they lie + the strings that do not fit them
     bool as_views[2] = {false, false};
     Buf h_views[2], d_views[2], h_long[2], d_long[2];
+    Buf h_bad; // pinned, one counter: view slots the device refused to copy (strsim_column_from_views_bounded); checked when the slice is finished
     uint64_t long_span[2] = {0, 0}; // bytes of h_long[s] to ship
     uint64_t r0 = 0, rows = 0;
     uint64_t bytes[2] = {0, 0};
+    uint64_t live() const
+    {
+        uint64_t b = h_out.cap + d_out.cap + h_bad.cap;
+        for (int i = 0; i < 2; ++i)
+            b += h_off[i].cap + h_val[i].cap + d_off[i].cap + d_val[i].cap + h_len[i].cap + d_len[i].cap + d_land[i].cap + h_views[i].cap +
+                 d_views[i].cap + h_long[i].cap + d_long[i].cap;
+        return b;
+    }
     bool direct = false; // this slice was computed in place on the pinned staging (see run(): launch)
     hipEvent_t ev_kernels = nullptr, ev_results = nullptr; // behind the slice's kernels (compute stream) / its D2H (copy stream)
     Slot() { for (int i = 0; i < 2; ++i) { d_off[i].device = true; d_val[i].device = true; d_len[i].device = true; d_land[i].device = true; d_views[i].device = true; d_long[i].device = true; } d_out.device = true; }
@@ -163,16 +179,16 @@ struct Slot {
     {
         for (int i = 0; i < 2; ++i) { h_off[i].release(); h_val[i].release(); d_off[i].release(); d_val[i].release(); h_len[i].release(); d_len[i].release(); d_land[i].release();
                                       h_views[i].release(); d_views[i].release(); h_long[i].release(); d_long[i].release(); }
-        h_out.release(); d_out.release();
+        h_out.release(); d_out.release(); h_bad.release();
         if (ev_kernels) (void)hipEventDestroy(ev_kernels);
         if (ev_results) (void)hipEventDestroy(ev_results);
         ev_kernels = ev_results = nullptr;
     }
 };
 
-// ---- device pipelines per calling thread (Polars may call from several of its threads at once) -----
+// ---- device pipelines, leased per call from one process-wide pool (Polars may call from many of its threads at once) -----
 // One pipeline = one device context + its stream, a copy stream for the results, three slots and the literal's buffers.  A
-// calling thread keeps one pipeline per entry of the device list (an ordinal may repeat: two pipelines on one GPU).
+// pipeline SET holds one pipeline per entry of the device list (an ordinal may repeat: two pipelines on one GPU).
 struct Pipe {
     strsim_ctx_t *ctx = nullptr;
     int device = 0;
@@ -180,6 +196,7 @@ struct Pipe {
     hipStream_t d2h = nullptr; // results travel back on their own stream: D2H of slice k runs beside H2D of slice k+1
     Buf lit_off, lit_val;     // device copy of a literal side
     Buf lit_h_off, lit_h_val; // its pinned host staging
+    uint64_t live() const { return slot[0].live() + slot[1].live() + slot[2].live() + lit_off.cap + lit_val.cap + lit_h_off.cap + lit_h_val.cap; }
     void close()
     {
         if (!ctx) return;
@@ -210,12 +227,122 @@ struct Pipe {
         return ctx;
     }
 };
-struct ThreadPipes {
+struct PipeSet {
     std::vector<Pipe *> p;
+    bool in_use = false;
+    uint64_t reserved = 0;  // what the call that holds the set asked for (its estimate; the set's real size may be larger)
+    uint64_t last_used = 0; // the pool's clock when the set came back
     Pipe &at(size_t i) { while (p.size() <= i) p.push_back(new Pipe); return *p[i]; }
-    ~ThreadPipes() { for (Pipe *q : p) delete q; }
+    uint64_t live() const { uint64_t b = 0; for (const Pipe *q : p) b += q->live(); return b; }
+    void close() { for (Pipe *q : p) q->close(); }
+    ~PipeSet() { for (Pipe *q : p) delete q; }
 };
-thread_local ThreadPipes g_pipes;
+
+// The staging of ALL calling threads against ONE budget (round 5 kept a set per calling thread, grow-only, for
+// as long as the thread lived -- an engine pool of 64-256 threads that each saw one large morsel pinned tens of GB, where the
+// reference's per-call scratch is three small vectors, strsim.rs:78-84, :109-123).  A call LEASES a set for its duration:
+//   * the most recently used idle set if there is one (its buffers are sized and warm), else a new one;
+//   * if the staging in use + this call's estimate would pass the budget, idle sets are released first (least recently used
+//     first), and if that is not enough the call WAITS for a running call to return -- unless no call is running: one call always
+//     proceeds, whatever it needs (the budget bounds what many calls pin together, never what one column requires);
+//   * when a set comes back and the process is over budget, idle sets are released (least recently used first) until it is not.
+// POLARS_STRSIM_STAGING_BUDGET_MB: pinned + device staging bytes, default 4096 (a 10 M-row call of cfg2's strings holds ~0.8 GB:
+// five such calls at full speed; 0 = no budget).  Output columns are pinned memory of their own, bounded in PinnedPool.
+class StagingPool {
+  public:
+    PipeSet *lease(uint64_t need)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            uint64_t in_use_bytes = 0, idle_bytes = 0;
+            size_t running = 0;
+            PipeSet *mru = nullptr;
+            for (PipeSet *s : sets_) {
+                if (s->in_use) { in_use_bytes += std::max(s->reserved, s->live()); ++running; continue; }
+                idle_bytes += s->live();
+                if (!mru || s->last_used > mru->last_used) mru = s;
+            }
+            const uint64_t mine = mru ? std::max(need, mru->live()) : need;
+            uint64_t others_idle = mru ? idle_bytes - mru->live() : 0;
+            while (budget_ && in_use_bytes + mine + others_idle > budget_ && others_idle) { // make room: the longest-idle sets go first
+                PipeSet *lru = nullptr;
+                for (PipeSet *s : sets_)
+                    if (!s->in_use && s != mru && s->live() && (!lru || s->last_used < lru->last_used)) lru = s;
+                if (!lru) break;
+                others_idle -= lru->live();
+                lru->close();
+                ++released_;
+            }
+            if (!budget_ || running == 0 || in_use_bytes + mine + others_idle <= budget_) {
+                PipeSet *s = mru;
+                if (!s) { s = new PipeSet; sets_.push_back(s); }
+                s->in_use = true;
+                s->reserved = need;
+                return s;
+            }
+            ++waits_;
+            cv_.wait(lk); // a running call returns its set (give_back)
+        }
+    }
+    void give_back(PipeSet *s)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            s->in_use = false;
+            s->reserved = 0;
+            s->last_used = ++clock_;
+            peak_ = std::max(peak_, g_live_pinned.load(std::memory_order_relaxed) + g_live_device.load(std::memory_order_relaxed));
+            while (budget_ && g_live_pinned.load(std::memory_order_relaxed) + g_live_device.load(std::memory_order_relaxed) > budget_) {
+                PipeSet *lru = nullptr;
+                for (PipeSet *q : sets_)
+                    if (!q->in_use && q->live() && (!lru || q->last_used < lru->last_used)) lru = q;
+                if (!lru) break; // (what is left belongs to running calls)
+                lru->close();
+                ++released_;
+            }
+            // (sets that hold nothing any more are dropped, so the list does not grow with every thread the engine ever had)
+            for (size_t i = 0; i < sets_.size();)
+                if (!sets_[i]->in_use && sets_[i]->live() == 0 && sets_.size() > 1 && sets_[i] != s) { delete sets_[i]; sets_.erase(sets_.begin() + (long)i); } else ++i;
+        }
+        cv_.notify_all();
+    }
+    // out[0..7] = live pinned bytes, live device bytes, budget bytes, sets, sets in use, sets released so far, calls that waited, peak live bytes seen at a return
+    void stats(uint64_t *out)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        out[0] = g_live_pinned.load(std::memory_order_relaxed);
+        out[1] = g_live_device.load(std::memory_order_relaxed);
+        out[2] = budget_;
+        out[3] = sets_.size();
+        out[4] = 0;
+        for (PipeSet *s : sets_) out[4] += s->in_use;
+        out[5] = released_;
+        out[6] = waits_;
+        out[7] = peak_;
+    }
+    void set_budget(uint64_t bytes) { std::lock_guard<std::mutex> lk(m_); budget_ = bytes; }
+
+  private:
+    static uint64_t budget_from_env()
+    {
+        const char *e = getenv("POLARS_STRSIM_STAGING_BUDGET_MB");
+        return (e && *e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)4096) << 20;
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<PipeSet *> sets_;
+    uint64_t budget_ = budget_from_env(), clock_ = 0, released_ = 0, waits_ = 0, peak_ = 0;
+};
+// (never destroyed: releasing device memory from a static destructor races the HIP runtime's own teardown; the OS takes it back)
+StagingPool &staging_pool() { static StagingPool *p = new StagingPool; return *p; }
+
+struct PipeLease {
+    PipeSet *set;
+    explicit PipeLease(uint64_t need) : set(staging_pool().lease(need)) {}
+    ~PipeLease() { staging_pool().give_back(set); }
+    PipeLease(const PipeLease &) = delete;
+    PipeLease &operator=(const PipeLease &) = delete;
+};
 
 // The devices a call uses.  Default: ONE device -- the calling thread's current HIP device (0 unless the host process chose
 // another; one process per GPU under a launcher keeps every process on its own).  POLARS_STRSIM_DEVICE = one ordinal.

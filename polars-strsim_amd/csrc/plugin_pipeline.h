@@ -38,10 +38,15 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
 {
     const size_t D = devs.size();
     ptimes.assign(D, PipeTimes{});
+    // this call's pipelines, leased for its duration (StagingPool): the estimate is three slots of the largest slice the call will
+    // cut, ~64 bytes a row on either side of the link (offsets or lengths + ~17-byte strings twice + the f64 result, with the slack
+    // Buf::reserve adds) -- the pool counts a set at its real size as soon as that is larger
+    const uint64_t need = 2 * 3 * std::min<uint64_t>(n, SLICE_ROWS * D) * 64;
+    PipeLease lease(need);
     std::vector<Pipe *> pipes(D);
     std::vector<hipStream_t> streams(D);
     for (size_t d = 0; d < D; ++d) {
-        pipes[d] = &g_pipes.at(d);
+        pipes[d] = &lease.set->at(d);
         streams[d] = static_cast<hipStream_t>(strsim_ctx_stream(pipes[d]->open(devs[d])));
     }
 
@@ -127,6 +132,10 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
         sl.direct = direct_call;
         for (int s = 0; s < 2; ++s)
             if (!lit[s] && sl.bytes[s] > direct_bytes()) sl.direct = false;
+        if (sl.as_views[0] || sl.as_views[1]) { // the device counts the slots it refuses (a malformed view cannot fault it): see finish()
+            sl.h_bad.reserve(64);
+            *static_cast<volatile uint32_t *>(sl.h_bad.p) = 0u;
+        }
         for (int s = 0; s < 2; ++s) {
             if (lit[s]) { doff[s] = lit_off_d[d]; dval[s] = lit_val_d[d]; drows[s] = 1; continue; }
             drows[s] = sl.rows;
@@ -144,7 +153,7 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
                 if (sl.long_span[s]) HIP_OR_FAIL(hipMemcpyAsync(sl.d_long[s].p, sl.h_long[s].p, sl.long_span[s], hipMemcpyHostToDevice, stream));
                 if (strsim_column_from_views_bounded(ctx, sl.d_views[s].p, sl.rows, static_cast<const uint8_t *>(sl.d_long[s].p), sl.long_span[s],
                                                      static_cast<uint32_t *>(sl.d_off[s].p), static_cast<uint8_t *>(sl.d_val[s].p),
-                                                     sl.bytes[s] + 64, nullptr) != STRSIM_OK)
+                                                     sl.bytes[s] + 64, static_cast<uint32_t *>(mapped(sl.h_bad.p))) != STRSIM_OK)
                     fail(strsim_last_error_message());
                 doff[s] = static_cast<const uint32_t *>(sl.d_off[s].p);
                 dval[s] = static_cast<const uint8_t *>(sl.d_val[s].p);
@@ -203,6 +212,10 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
             if (strsim_ctx_retire_oldest(ctx) != STRSIM_OK) fail(strsim_last_error_message()); // also the deferred slow-row and long-string passes
         }
         t1.stop(ptimes[d].t_wait);
+        //  view-native slices: a slot the device skipped would be a row computed on zeroed bytes -- an error, never silence
+        if ((sl.as_views[0] || sl.as_views[1]) && *static_cast<volatile uint32_t *>(sl.h_bad.p) != 0u)
+            fail("internal: " + std::to_string(*static_cast<volatile uint32_t *>(sl.h_bad.p)) + " string views of rows " + std::to_string(sl.r0) + ".." +
+                 std::to_string(sl.r0 + sl.rows) + " point outside the bytes shipped with them");
         const bool via_slot = sl.direct || !out_pinned;
         if (strsim_ctx_last_late_rows(ctx) != 0 && !sl.direct) { // rows finished by a pass launched just now: fetch the column again
             t1.start();

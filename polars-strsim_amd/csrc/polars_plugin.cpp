@@ -169,6 +169,9 @@ uint32_t _polars_plugin_get_version(void) { return (POLARS_PLUGIN_VERSION_MAJOR 
 
 const char *_polars_plugin_get_last_error_message(void) { return g_plugin_error.c_str(); }
 
+void _polars_plugin_strsim_staging_stats(uint64_t out[8]) { if (out) staging_pool().stats(out); }
+void _polars_plugin_strsim_staging_set_budget_mb(uint64_t megabytes) { staging_pool().set_budget(megabytes << 20); }
+
 #define POLARS_PLUGIN_DEFINE(name, id)                                                                          \
     void _polars_plugin_##name(SeriesExport *inputs, size_t n_inputs, const uint8_t *, size_t,                  \
                                SeriesExport *return_value, CallerContext *cc)                                   \

@@ -113,38 +113,33 @@ struct strsim_ctx {
     bool timing = false;
     double lane_ms = 0, wave_ms = 0;
     uint64_t lane_launches = 0, wave_launches = 0;
+    // environment knobs, read ONCE in strsim_ctx_create (not on the launch path: a small call is ~23 us, and a host that calls
+    // setenv concurrently must not race a getenv of ours per call)
+    bool no_literal_path = false;      // STRSIM_NO_LITERAL_PATH (tuning / A-B knob)
+    int wide_cap_per_cu = 192;         // STRSIM_WIDE_WG_PER_CU (tuning knob)
+    int huge_waves_per_cu = 16;        // STRSIM_HUGE_WAVES_PER_CU (tuning knob); 8 KB of LDS per Levenshtein wave
+    uint64_t host_direct_rows = 65536; // STRSIM_HOST_DIRECT_ROWS=0 switches strsim_pairs_host's in-place path off (tests do)
+    // fault injection (tests only): the k-th slot retirement of this context fails with STRSIM_ERR_INTERNAL -- the one way to see
+    // STRSIM_ERR_EARLIER_CALL and the "a slot is retired whatever fails" rule without breaking the device
+    uint64_t fault_retire_at = 0;      // STRSIM_FAULT_RETIRE_AT (0 = never)
+    uint64_t retired = 0;
 };
 
 static int ctx_set_device(strsim_ctx *c) { HIP_TRY(hipSetDevice(c->device)); return STRSIM_OK; }
 
 static int ctx_reserve(void **p, size_t *cap, size_t bytes);
 
-static int huge_waves_per_cu()
-{
-    int v = 16; // STRSIM_HUGE_WAVES_PER_CU overrides (tuning knob); 8 KB of LDS per Levenshtein wave
-    if (const char *env = getenv("STRSIM_HUGE_WAVES_PER_CU")) {
-        const int e = atoi(env);
-        if (e >= 1 && e <= 32) v = e;
-    }
-    return v;
-}
-
 // strsim_pairs_host computes calls up to this size in place on pinned host memory (see there).  Measured through ctypes
 // (bench_support/bench_small_host_calls.py), in place vs copies: 37 vs 70 us at 1..100 rows, 57 vs 95 us at 10 000,
 // 92 vs 117 us at 32 768, 150 vs 171 us at 70 000, 246 vs 207 us at 100 000 -- hence the limit.
 static constexpr size_t HOST_DIRECT_BYTES = (size_t)2 << 20;
-static uint64_t host_direct_rows() // read per call: STRSIM_HOST_DIRECT_ROWS=0 switches the path off (tests do)
-{
-    const char *e = getenv("STRSIM_HOST_DIRECT_ROWS");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)65536;
-}
 
 // Rows with a string longer than STRSIM_WAVE_PATH_MAX_BYTES: rerun them with the scratch arrays in global memory.
 static int ctx_run_huge(strsim_ctx *c, int slot, const DevStatus &st)
 {
     const uint32_t cap = (st.max_len + 63u) & ~63u;
     const size_t per_wave = (size_t)HUGE_WS_WORDS(cap) * sizeof(uint32_t);
-    const size_t max_waves = (size_t)c->num_cu * (size_t)huge_waves_per_cu();
+    const size_t max_waves = (size_t)c->num_cu * (size_t)c->huge_waves_per_cu;
     size_t waves = st.huge_rows < max_waves ? st.huge_rows : max_waves;
     const size_t budget = (size_t)4 << 30; // keep the workspace under 4 GiB
     if (waves * per_wave > budget) waves = budget / per_wave ? budget / per_wave : 1;
@@ -228,6 +223,11 @@ static int ctx_retire_slot(strsim_ctx *c, int s)
     if (!ctx_slot_published(c, s)) { // (cannot happen behind a stream synchronise; strsim_ctx_retire_oldest checks before it gets here)
         c->slot_timed[s] = c->slot_deferred[s] = false;
         set_error("internal: the status block of a completed call was not published (slot %d)", s);
+        return STRSIM_ERR_INTERNAL;
+    }
+    if (c->fault_retire_at && ++c->retired == c->fault_retire_at) { // (tests only: STRSIM_FAULT_RETIRE_AT)
+        c->slot_timed[s] = c->slot_deferred[s] = false;
+        set_error("fault injected at retirement %llu of this context (STRSIM_FAULT_RETIRE_AT)", (unsigned long long)c->retired);
         return STRSIM_ERR_INTERNAL;
     }
     const uint32_t left = *reinterpret_cast<const volatile uint32_t *>(&c->status_host[s].lane_left);
@@ -345,6 +345,17 @@ int strsim_ctx_create(int device, void *hip_stream, strsim_ctx_t **out_ctx)
         const int v = atoi(env);
         if (v >= 1 && v <= 256) c->lev_waves_per_cu = v;
     }
+    c->no_literal_path = getenv("STRSIM_NO_LITERAL_PATH") != nullptr;
+    if (const char *env = getenv("STRSIM_WIDE_WG_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 4096) c->wide_cap_per_cu = v;
+    }
+    if (const char *env = getenv("STRSIM_HUGE_WAVES_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 32) c->huge_waves_per_cu = v;
+    }
+    if (const char *env = getenv("STRSIM_HOST_DIRECT_ROWS")) c->host_direct_rows = (uint64_t)strtoull(env, nullptr, 10);
+    if (const char *env = getenv("STRSIM_FAULT_RETIRE_AT")) c->fault_retire_at = (uint64_t)strtoull(env, nullptr, 10);
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -493,17 +504,10 @@ static int pairs_device_impl(strsim_ctx_t *c, int measure, const uint32_t *a_off
     la.worklist = reinterpret_cast<uint32_t *>(c->slowmask[mb] + 2 * nchunks);
     la.qtab = c->qtab;
     la.stage_grid = c->num_cu * c->stage_wg_per_cu;
-    la.no_literal_path = getenv("STRSIM_NO_LITERAL_PATH") != nullptr; // (tuning / A-B knob)
+    la.no_literal_path = c->no_literal_path;
     la.long_rows = c->long_rows;
     la.wide_grid = c->num_cu * 3; // resident (LDS)
-    {
-        int wide_cap_per_cu = 192; // STRSIM_WIDE_WG_PER_CU overrides (tuning knob)
-        if (const char *env = getenv("STRSIM_WIDE_WG_PER_CU")) {
-            const int v = atoi(env);
-            if (v >= 1 && v <= 4096) wide_cap_per_cu = v;
-        }
-        la.wide_grid_cap = c->num_cu * wide_cap_per_cu;
-    }
+    la.wide_grid_cap = c->num_cu * c->wide_cap_per_cu;
     la.wave_grid = c->num_cu * 16;                       // k_wave_pairs, other measures: 4 waves per SIMD
     la.wave_grid_lev = c->num_cu * c->lev_waves_per_cu;
     {   // per-wave global scratch of k_wave_pairs (scalar-value arrays; Levenshtein: text arenas as well)
@@ -670,7 +674,7 @@ int strsim_pairs_host(strsim_ctx_t *c, int measure, const uint32_t *a_off, const
     int rc = ctx_set_device(c);
     if (rc) return rc;
     const size_t abytes = (size_t)a_off[a_rows] - a_off[0], bbytes = (size_t)b_off[b_rows] - b_off[0];
-    if (n <= host_direct_rows() && abytes <= HOST_DIRECT_BYTES && bbytes <= HOST_DIRECT_BYTES) {
+    if (n <= c->host_direct_rows && abytes <= HOST_DIRECT_BYTES && bbytes <= HOST_DIRECT_BYTES) {
         // Small call: gather the five buffers in one pinned block and let the kernels work on it in place through the
         // device's mapping of host memory -- no copy engine, whose hand-overs (four H2D, one D2H) are most of a small call.
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -761,5 +765,7 @@ int strsim_ctx_set_stream_ordered(strsim_ctx_t *c, int enable)
     c->stream_ordered = enable != 0;
     return STRSIM_OK;
 }
+
+int strsim_ctx_get_stream_ordered(strsim_ctx_t *c) { return c ? (c->stream_ordered ? 1 : 0) : 1; }
 
 } // extern "C"

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view_column(const uint4 *__res
     __syncthreads();
     unsigned long long run = 0;
     for (int w = 0; w < VIEW_THREADS / 64; ++w) run += s_part64[w];
-    const unsigned long long cap = values_bytes < (1ull << 32) ? values_bytes : (1ull << 32); // (offsets are 32 bits)
+    // (offsets are 32 bits, and the block sums SATURATE at 2^32 - 1: an end offset of 2^32 - 1 or more is out of range whatever the
+    //  caller stated -- ADVICE r5: with the extents not stated, a one-byte row behind a saturated sum passed `<= 2^32` and was written
+    //  at values + 0xFFFFFFFF)
+    const unsigned long long cap = values_bytes < 0xFFFFFFFEull ? values_bytes : 0xFFFFFFFEull;
     if (blockIdx.x == 0 && tid == 0) off[0] = 0u;
 #pragma unroll 1
     for (int k = 0; k < VIEW_STRIPS; ++k) {

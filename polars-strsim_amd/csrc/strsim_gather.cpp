@@ -13,33 +13,36 @@
 #include <dlfcn.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 
 #include "strsim_amd.h"
 #include "strsim_internal.h"
+#include "strsim_rccl_abi.h"
 
 using strsim::hip_fail;
 using strsim::set_error;
 
 namespace {
 
-// (declared here rather than through <rccl/rccl.h>: the build must not need the header either; RCCL keeps NCCL's ABI)
-typedef struct { char internal[STRSIM_GATHER_ID_BYTES]; } UniqueId;
-typedef void *Comm;
-constexpr int NCCL_SUCCESS = 0, NCCL_FLOAT64 = 8;
+// (declared by hand in strsim_rccl_abi.h rather than through <rccl/rccl.h>: the build must not need the header either)
+using namespace strsim_rccl;
+static_assert(ID_BYTES == STRSIM_GATHER_ID_BYTES, "the unique id of include/strsim_amd.h is RCCL's");
+constexpr int NCCL_SUCCESS = SUCCESS, NCCL_FLOAT64 = FLOAT64;
 
 struct Rccl {
     void *handle = nullptr;
-    int (*GetUniqueId)(UniqueId *) = nullptr;
-    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
-    int (*CommDestroy)(Comm) = nullptr;
-    int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    GetUniqueIdFn GetUniqueId = nullptr;
+    CommInitRankFn CommInitRank = nullptr;
+    CommDestroyFn CommDestroy = nullptr;
+    SendFn Send = nullptr;
+    RecvFn Recv = nullptr;
+    GroupFn GroupStart = nullptr;
+    GroupFn GroupEnd = nullptr;
+    GetErrorStringFn GetErrorString = nullptr;
+    CommCountFn CommCount = nullptr;
     bool ok = false;
 };
 
@@ -49,6 +52,13 @@ Rccl &rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so"};
+        // STRSIM_RCCL_LIB: the collectives library to use, by path -- for a host whose RCCL is not on the loader's path (and for the
+        // tests' stand-in transport, tests/cpu_harness/fake_rccl.cpp, which lets several ranks share the one GPU of a test box)
+        if (const char *path = getenv("STRSIM_RCCL_LIB"))
+            if (*path) {
+                r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+                if (!r.handle) return; // (named and not loadable: an error, never a silent other copy)
+            }
         for (const char *n : names) // a copy the process already holds (torch's, the host application's) wins
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char *n : names)
@@ -63,6 +73,7 @@ Rccl &rccl()
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     });
     return r;
@@ -125,15 +136,13 @@ int strsim_gather_create(strsim_ctx_t *ctx, const uint8_t id[STRSIM_GATHER_ID_BY
     return STRSIM_OK;
 }
 
-int strsim_gather_f64(strsim_gather_t *g, const double *shard, double *column, uint64_t total_rows, int root)
+// One gather over an explicit partition: rank r holds rows [off(r), off(r) + len(r)) of the column.
+static int gather_ranges(strsim_gather_t *g, const double *shard, double *column, const uint64_t *ranges, int root, const char *who)
 {
-    if (!g) { set_error("strsim_gather_f64: NULL gatherer"); return STRSIM_ERR_ARG; }
-    if (root < 0 || root >= g->world) { set_error("strsim_gather_f64: root %d of %d ranks", root, g->world); return STRSIM_ERR_ARG; }
-    // the reference's partition (strsim.rs:21-39): rows / world each, the remainder to the last rank
-    const uint64_t chunk = g->world == 1 ? total_rows : total_rows / (uint64_t)g->world;
-    auto rows_of = [&](int r) { return r == g->world - 1 ? total_rows - chunk * (uint64_t)(g->world - 1) : chunk; };
-    const uint64_t mine = rows_of(g->rank);
-    if ((mine && !shard) || (g->rank == root && total_rows && !column)) { set_error("strsim_gather_f64: NULL buffer"); return STRSIM_ERR_ARG; }
+    const uint64_t mine = ranges[2 * g->rank + 1];
+    uint64_t others = 0;
+    for (int r = 0; r < g->world; ++r) others += r == g->rank ? 0 : ranges[2 * r + 1];
+    if ((mine && !shard) || (g->rank == root && (mine || others) && !column)) { set_error("%s: NULL buffer", who); return STRSIM_ERR_ARG; }
     hipError_t e = hipSetDevice(g->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     hipStream_t st = (hipStream_t)strsim_ctx_stream(g->ctx);
@@ -141,17 +150,55 @@ int strsim_gather_f64(strsim_gather_t *g, const double *shard, double *column, u
     if (rc != NCCL_SUCCESS) return nccl_fail(rc, "ncclGroupStart");
     if (g->rank == root) {
         for (int r = 0; r < g->world && rc == NCCL_SUCCESS; ++r)
-            if (r != root && rows_of(r)) rc = rccl().Recv(column + chunk * (uint64_t)r, rows_of(r), NCCL_FLOAT64, r, g->comm, st);
+            if (r != root && ranges[2 * r + 1]) rc = rccl().Recv(column + ranges[2 * r], ranges[2 * r + 1], NCCL_FLOAT64, r, g->comm, st);
     } else if (mine) {
         rc = rccl().Send(shard, mine, NCCL_FLOAT64, root, g->comm, st);
     }
     const int rc2 = rccl().GroupEnd();
     if (rc != NCCL_SUCCESS) return nccl_fail(rc, "ncclSend / ncclRecv");
     if (rc2 != NCCL_SUCCESS) return nccl_fail(rc2, "ncclGroupEnd");
-    if (g->rank == root && mine && column + chunk * (uint64_t)root != shard) { // the root's own shard: a device copy, same stream
-        e = hipMemcpyAsync(column + chunk * (uint64_t)root, shard, mine * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (g->rank == root && mine && column + ranges[2 * root] != shard) { // the root's own shard: a device copy, same stream
+        e = hipMemcpyAsync(column + ranges[2 * root], shard, mine * sizeof(double), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
     }
+    return STRSIM_OK;
+}
+
+int strsim_gather_f64(strsim_gather_t *g, const double *shard, double *column, uint64_t total_rows, int root)
+{
+    if (!g) { set_error("strsim_gather_f64: NULL gatherer"); return STRSIM_ERR_ARG; }
+    if (root < 0 || root >= g->world) { set_error("strsim_gather_f64: root %d of %d ranks", root, g->world); return STRSIM_ERR_ARG; }
+    // the reference's partition (strsim.rs:21-39): rows / world each, the remainder to the last rank
+    uint64_t stack[2 * 16], *ranges = stack;
+    if (g->world > 16) { ranges = new (std::nothrow) uint64_t[2 * (size_t)g->world]; if (!ranges) return STRSIM_ERR_OOM; }
+    strsim_split_offsets(total_rows, (uint64_t)g->world, ranges);
+    const int rc = gather_ranges(g, shard, column, ranges, root, "strsim_gather_f64");
+    if (ranges != stack) delete[] ranges;
+    return rc;
+}
+
+int strsim_gather_f64_ranges(strsim_gather_t *g, const double *shard, double *column, const uint64_t *ranges, int root)
+{
+    if (!g || !ranges) { set_error("strsim_gather_f64_ranges: NULL argument"); return STRSIM_ERR_ARG; }
+    if (root < 0 || root >= g->world) { set_error("strsim_gather_f64_ranges: root %d of %d ranks", root, g->world); return STRSIM_ERR_ARG; }
+    for (int r = 0; r < g->world; ++r) // the ranks' ranges must not overlap (a receive would race another, or the root's own copy)
+        for (int q = 0; q < r; ++q) {
+            const uint64_t a0 = ranges[2 * q], a1 = a0 + ranges[2 * q + 1], b0 = ranges[2 * r], b1 = b0 + ranges[2 * r + 1];
+            if (ranges[2 * q + 1] && ranges[2 * r + 1] && a0 < b1 && b0 < a1) {
+                set_error("strsim_gather_f64_ranges: the rows of rank %d and rank %d overlap", q, r);
+                return STRSIM_ERR_ARG;
+            }
+        }
+    return gather_ranges(g, shard, column, ranges, root, "strsim_gather_f64_ranges");
+}
+
+int strsim_gather_comm_count(strsim_gather_t *g, int *count)
+{
+    if (!g || !count) { set_error("strsim_gather_comm_count: NULL argument"); return STRSIM_ERR_ARG; }
+    *count = 0;
+    if (!rccl().CommCount) { set_error("strsim_gather_comm_count: this RCCL has no ncclCommCount"); return STRSIM_ERR_NO_DEVICE; }
+    const int rc = rccl().CommCount(g->comm, count);
+    if (rc != NCCL_SUCCESS) return nccl_fail(rc, "ncclCommCount");
     return STRSIM_OK;
 }
 

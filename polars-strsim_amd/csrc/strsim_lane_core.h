@@ -396,9 +396,13 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
 #pragma unroll
     for (int g = 0; g < 32 / COLS_PER_TEST; ++g) {
         if ((uint32_t)(COLS_PER_TEST * g) >= tmax) break;
-        auto column = [&](int i) {
+        auto column = [&](int i, bool live) {
             const uint32_t Eq = eq_mask<NP>(P, valid, wa[i >> 2], i & 3);
-            if (DO_JARO && KEEP_EQ) E[(DO_JARO && KEEP_EQ) ? i : 0] = Eq; // (a column past the end of a: never looked at, its flag is clear)
+            // KEEP_EQ: the zip pass reads E[i] of EVERY column of a visited group (masked by a clear flag for columns past the end
+            // of a), so it is written for every such column too -- outside the lane's `i < la` predicate (an
+            // indeterminate read otherwise; at most COLS_PER_TEST - 1 extra masks per pair, in the text's last group only)
+            if (DO_JARO && KEEP_EQ) E[(DO_JARO && KEEP_EQ) ? i : 0] = Eq;
+            if (!live) return;
             if (DO_LEV) {
                 const uint32_t D0 = bitop3<0xBE>((Eq & Pv) + Pv, Pv, Eq) | Mv; // (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv
                 const uint32_t nHP = bitop3<0x0E>(Mv, D0, Pv);                 // ~HP = ~Mv & (D0 | Pv)
@@ -421,11 +425,13 @@ STRSIM_HD void lane_cores32(const uint32_t (&wa)[8], uint32_t la, uint32_t tmin,
         };
         if ((uint32_t)(COLS_PER_TEST * (g + 1)) >= tmin) {                 // (uniform) some lane's text may end in this group
 #pragma unroll
-            for (int jj = 0; jj < COLS_PER_TEST; ++jj)
-                if ((uint32_t)(COLS_PER_TEST * g + jj) < la) column(COLS_PER_TEST * g + jj);
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj) {
+                const bool live = (uint32_t)(COLS_PER_TEST * g + jj) < la;
+                if ((DO_JARO && KEEP_EQ) || live) column(COLS_PER_TEST * g + jj, live);
+            }
         } else {
 #pragma unroll
-            for (int jj = 0; jj < COLS_PER_TEST; ++jj) column(COLS_PER_TEST * g + jj);
+            for (int jj = 0; jj < COLS_PER_TEST; ++jj) column(COLS_PER_TEST * g + jj, true);
         }
     }
     if (DO_LEV) {

@@ -8,7 +8,7 @@ validity mask), as in README.md:69-70.
 """
 import numpy as np
 
-from ._lib import MEASURES, MEASURE_ID, LIB_PATH, ShapeMismatch, StrsimError, lib
+from ._lib import MEASURES, MEASURE_ID, LIB_PATH, STATUS, ShapeMismatch, StrsimError, lib
 from .context import Codec, Context, device_count, pack_strings, split_offsets
 
 _default_ctx = None
@@ -68,4 +68,4 @@ def sorensen_dice(a, b, ctx=None):
 
 
 __all__ = ["Codec", "Context", "device_count", "pack_strings", "split_offsets", "similarity", "levenshtein", "jaro",
-           "jaro_winkler", "jaccard", "sorensen_dice", "MEASURES", "MEASURE_ID", "ShapeMismatch", "StrsimError"]
+           "jaro_winkler", "jaccard", "sorensen_dice", "MEASURES", "MEASURE_ID", "STATUS", "ShapeMismatch", "StrsimError"]

@@ -15,7 +15,7 @@ MEASURES = ("levenshtein", "jaro", "jaro_winkler", "jaccard", "sorensen_dice")  
 MEASURE_ID = {m: i for i, m in enumerate(MEASURES)}
 
 STATUS = {0: "OK", 1: "ERR_SHAPE", 2: "ERR_ARG", 3: "ERR_NO_DEVICE", 4: "ERR_HIP", 5: "ERR_OOM", 6: "ERR_DTYPE",
-          7: "ERR_INTERNAL"}
+          7: "ERR_INTERNAL", 8: "ERR_EARLIER_CALL"}
 
 
 class StrsimError(RuntimeError):
@@ -139,6 +139,12 @@ def lib():
     L.strsim_gather_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     L.strsim_gather_f64.restype = i32
     L.strsim_gather_f64.argtypes = [vp, vp, vp, u64, i32]
+    L.strsim_ctx_get_stream_ordered.restype = i32
+    L.strsim_ctx_get_stream_ordered.argtypes = [vp]
+    L.strsim_gather_f64_ranges.restype = i32
+    L.strsim_gather_f64_ranges.argtypes = [vp, vp, vp, vp, i32]
+    L.strsim_gather_comm_count.restype = i32
+    L.strsim_gather_comm_count.argtypes = [vp, C.POINTER(i32)]
     L.strsim_gather_destroy.restype = None
     L.strsim_gather_destroy.argtypes = [vp]
     L.strsim_codec_decode_gathered_from.restype = i32

@@ -96,6 +96,11 @@ class Context:
         check(lib().strsim_ctx_set_stream_ordered(self._h, 1 if enable else 0))
 
     @property
+    def stream_ordered(self):
+        """The mode the next call is enqueued in (strsim_ctx_get_stream_ordered, ABI 1.6): True = every kernel up front."""
+        return bool(lib().strsim_ctx_get_stream_ordered(self._h))
+
+    @property
     def last_long_rows(self):
         """Rows with a string beyond the wave-kernel cap among the calls the last synchronize() retired."""
         return int(lib().strsim_ctx_last_long_rows(self._h))

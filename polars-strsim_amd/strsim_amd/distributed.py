@@ -32,15 +32,20 @@ def shard_ranges(n_rows, world_size, root_share=1.0):
     return [(0, r0)] + [(r0 + o, ln) for o, ln in rest]
 
 
-def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=None):
+def gather_column(local, n_rows, dst=0, group=None, async_op=False, recv_buffer=None, parts=None):
     """Gather the per-rank result shards (1-D tensors laid out by shard_range) onto `dst`.
 
+    `parts`: the ranks' (offset, len) when they are not split_offsets(n_rows, world) -- shard_ranges(..., root_share); the receive
+    buffer (world x the longest shard) is laid out rank by rank either way.
     Returns the assembled [n_rows] tensor on dst (None elsewhere); with async_op=True returns
     (work, finish) where finish() yields that tensor after work.wait().
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    parts = split_offsets(n_rows, world)
+    if parts is None:
+        parts = split_offsets(n_rows, world)
+    elif len(parts) != world or sum(p[1] for p in parts) != n_rows:
+        raise ValueError(f"gather_column: parts must hold one (offset, len) per rank and cover {n_rows} rows")
     cap = max(p[1] for p in parts)
     if local.numel() != parts[rank][1]:
         raise ValueError(f"rank {rank}: shard has {local.numel()} rows, expected {parts[rank][1]}")
@@ -89,12 +94,29 @@ class AbiGather:
         ub = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(bytes(uid))
         check(lib().strsim_gather_create(ctx._h, ub, self.world, self.rank, C.byref(self._h)))
 
-    def gather(self, shard, column, total_rows, root=0):
+    def gather(self, shard, column, total_rows=None, root=0, parts=None):
         """shard: this rank's f64 rows (torch CUDA tensor, split_offsets(total_rows, world)[rank] of them); column: the root's
-        [total_rows] f64 tensor (None elsewhere).  Asynchronous on the context's stream."""
+        [total_rows] f64 tensor (None elsewhere).  Asynchronous on the context's stream.
+        `parts` = [(offset, len)] * world: an explicit partition instead (strsim_gather_f64_ranges, ABI 1.6)."""
+        import ctypes as C
         from ._lib import check, lib
-        check(lib().strsim_gather_f64(self._h, shard.data_ptr() if shard is not None and shard.numel() else None,
-                                      column.data_ptr() if column is not None else None, int(total_rows), int(root)))
+        sp = shard.data_ptr() if shard is not None and shard.numel() else None
+        cp = column.data_ptr() if column is not None else None
+        if parts is None:
+            check(lib().strsim_gather_f64(self._h, sp, cp, int(total_rows), int(root)))
+            return
+        if len(parts) != self.world:
+            raise ValueError("AbiGather.gather: one (offset, len) per rank")
+        flat = (C.c_uint64 * (2 * self.world))(*[int(v) for p in parts for v in p])
+        check(lib().strsim_gather_f64_ranges(self._h, sp, cp, flat, int(root)))
+
+    def comm_count(self):
+        """The rank count of the RCCL communicator itself (ncclCommCount through strsim_gather_comm_count)."""
+        import ctypes as C
+        from ._lib import check, lib
+        n = C.c_int(0)
+        check(lib().strsim_gather_comm_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def close(self):
         from ._lib import lib
@@ -124,9 +146,12 @@ class ShardGatherer:
     """
 
     def __init__(self, ctx, compute_stream, measures, rows, device, backend="nccl", codec_chars=None, parts=None,
-                 exc_ship=65536, root_plain=True):
+                 exc_ship=65536, root_plain=True, impl="torch"):
         """`compute_stream`: the torch stream whose handle `ctx` was created with (the kernels' stream).
-        `rows`: this rank's shard length when `parts` is None (every rank the same), else ignored."""
+        `rows`: this rank's shard length when `parts` is None (every rank the same), else ignored.
+        `impl`: "torch" = torch.distributed.gather (equal counts: shards padded to the longest); "abi" = the C ABI's own gather
+        (strsim_gather_f64_ranges: grouped RCCL send / recv of the ragged f64 shards straight into the root's column, the unique id
+        broadcast through torch.distributed) -- raw f64 only, so `codec_chars` must be None.  Collective: every rank constructs."""
         import strsim_amd as S
         if ctx.stream != compute_stream.cuda_stream:
             raise ValueError("ShardGatherer: ctx does not enqueue on compute_stream")
@@ -163,6 +188,15 @@ class ShardGatherer:
                     self.codecs = {}
                     break
         self.codes, self.done = {}, {}
+        self.impl, self.abi = impl, None
+        if impl not in ("torch", "abi"):
+            raise ValueError("ShardGatherer: impl is 'torch' or 'abi'")
+        if impl == "abi":
+            if self.codecs or codec_chars:
+                raise ValueError("ShardGatherer: the C ABI's gather ships raw f64 (codec_chars=None)")
+            box = [AbiGather.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.abi = AbiGather(self.ctx_comm, box[0], self.world, self.rank)  # (collective: ncclCommInitRank)
         root = self.rank == 0
         self.recv = torch.empty(self.total, dtype=torch.float64, device=device) if root else None
         self.recv_codes = None
@@ -178,9 +212,9 @@ class ShardGatherer:
         if self.codecs and root:  # codes travel as bytes: neither RCCL nor gloo has a 16-bit integer type
             self.recv_codes = [torch.empty(self.world * self.ship_bytes, dtype=torch.uint8, device="cpu" if self.host else device)
                                for _ in range(2)]
-        elif root and self.host:
+        elif root and self.host and self.abi is None:
             self.recv_host = torch.empty(self.world * self.cap_rows, dtype=torch.float64)
-        if not self.codecs and root and not self.host:
+        if not self.codecs and root and not self.host and self.abi is None:
             self.recv_pad = torch.empty(self.world * self.cap_rows, dtype=torch.float64, device=device) \
                 if any(p[1] != self.cap_rows for p in self.parts) else None
 
@@ -195,7 +229,7 @@ class ShardGatherer:
     @property
     def transport(self):
         if not self.codecs:
-            return "f64"
+            return "f64 (strsim_gather_f64_ranges: grouped RCCL send/recv)" if self.abi is not None else "f64"
         return "%d-bit codes, packed" % max(c.bits for c in self.codecs.values()) if self.packed else "u16 codes"
 
     def wait_slot(self, slot):
@@ -268,6 +302,9 @@ class ShardGatherer:
                         self.decoded[b].record(self.decode)
                         if self.timing:
                             self._t_dec.append((d0, self.decoded[b]))
+            elif self.abi is not None:
+                # ragged shards straight into their places of the root's column, on this (the comm) stream
+                self.abi.gather(out, self.recv, parts=self.parts, root=0)
             else:
                 ragged = any(p[1] != self.cap_rows for p in self.parts)
                 src = out.cpu() if self.host else out
@@ -276,7 +313,7 @@ class ShardGatherer:
                 else:
                     rb = None
                 # (gather_column pads the shorter shards itself and needs the caller's row count to be the real total)
-                work, _ = gather_column(src, self.total, dst=0, async_op=True, recv_buffer=rb)
+                work, _ = gather_column(src, self.total, dst=0, async_op=True, recv_buffer=rb, parts=self.parts)
                 work.wait()
                 if self.rank == 0 and ragged and not self.host:
                     for r, (off, ln) in enumerate(self.parts):
@@ -291,9 +328,18 @@ class ShardGatherer:
         """Rank 0, after drain(): the gathered f64 column of the last shipment (total rows); None elsewhere."""
         if self.rank != 0:
             return None
-        if self.host and not self.codecs:
+        if self.host and not self.codecs and self.abi is None:
             return torch.cat([self.recv_host[r * self.cap_rows:r * self.cap_rows + ln] for r, (_o, ln) in enumerate(self.parts)]).to(self.dev)
         return self.recv
+
+    def comm_ranks(self):
+        """impl "abi": the rank count RCCL's communicator reports for itself; None for torch.distributed's gather."""
+        return self.abi.comm_count() if self.abi is not None else None
+
+    def close(self):
+        if self.abi is not None:
+            self.abi.close()
+            self.abi = None
 
     def drain(self):
         self.comm.synchronize()

@@ -14,6 +14,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _duplicate_test_names(path):
+    """Top-level `def test_*` / `class Test*` names defined more than once in a file.  Python keeps the LAST definition, so the
+    earlier test silently never runs and pytest cannot see it (tests/test_gpu_parity.py carried one for a round)."""
+    import ast
+    seen, dup = set(), []
+    for node in ast.parse(open(path, encoding="utf-8").read(), filename=path).body:
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)) and node.name.lower().startswith("test"):
+            if node.name in seen:
+                dup.append("%s:%d %s" % (os.path.basename(path), node.lineno, node.name))
+            seen.add(node.name)
+    return dup
+
+
+def pytest_collectstart(collector):
+    # (a collection ERROR, not a warning: the run fails until the shadowed test is given a name of its own)
+    path = str(getattr(collector, "path", "") or "")
+    if isinstance(collector, pytest.Module) and os.path.basename(path).startswith("test_"):
+        dup = _duplicate_test_names(path)
+        if dup:
+            raise pytest.UsageError("duplicate top-level test names (the earlier definition is dead code): " + ", ".join(dup))
+
+
 def _have_gpu():
     try:
         import torch
@@ -26,7 +48,7 @@ def _have_gpu():
 # (C-ABI symbols, then the whole Polars-plugin ABI on the GPU, then the thin-ABI parity suite), the cheap suites next, and
 # the minutes-long full-size / fuzz files last -- whatever the alphabet says.
 _FILE_ORDER = ["test_abi_symbols.py", "test_plugin_abi_gpu.py", "test_plugin_configs_gpu.py", "test_hip_runtime_sharing.py",
-               "test_gpu_parity.py", "test_gpu_multirank_smoke.py", "test_packaging.py", "test_installed_wheel_gpu.py"]
+               "test_gpu_parity.py", "test_gpu_multirank_smoke.py", "test_gather_abi.py", "test_packaging.py", "test_installed_wheel_gpu.py"]
 _FILE_LAST = ["test_knobs_gpu.py", "test_gpu_hypothesis.py", "test_gpu_fuzz.py", "test_gpu_fullsize.py"]
 
 

@@ -669,7 +669,7 @@ def test_one_launch_calls_and_deferred_slow_rows(S, measure):
             assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "%s, in flight, %d slow rows" % (measure, k))
 
 
-def test_more_calls_in_flight_than_the_ring_holds(S):
+def test_ring_wrap_with_a_slow_row_call_and_an_eager_small_call(S):
     """40 one-launch calls enqueued back to back without a single retirement -- more than the context's ring of 32 status
     slots -- one of them with slow rows.  At the wrap the library retires what is pending inside strsim_pairs_device (documented);
     what that finished late is carried to the caller's next retirement, and every result is the oracle's."""
@@ -683,14 +683,66 @@ def test_more_calls_in_flight_than_the_ring_holds(S):
         for o, k in zip(outs, order):
             assert_bit_exact(o.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "ring wrap, %d slow rows" % k)
         # an eager small call that leaves nothing pending does not wipe what pending calls still have to report
-        small = tuple(t[:101] if i % 2 == 0 else t for i, t in enumerate(frames[0][2]))
         ctx.pairs_device("jaro", *frames[700][2])  # (pending, one launch, slow rows inside)
-        import numpy as _np
         A, B = frames[0][0][:100], frames[0][1][:100]
         oa, va = S.pack_strings(A)
         ob, vb = S.pack_strings(B)
         got = ctx.pairs_host("jaro", oa, va, ob, vb)  # the in-place host path: strsim_pairs_device_small + synchronize
         assert_bit_exact(got, O.batch_strings("jaro", A, B, 2), A, B, "small call beside a pending one")
+        # (pairs_host synchronised the context: the pending call was retired there and its slow rows were reported, not wiped)
+        assert ctx.last_late_rows >= 700
+
+
+def test_failed_retirement_at_the_ring_wrap_is_reported_as_an_earlier_call(S, monkeypatch):
+    """STRSIM_ERR_EARLIER_CALL (include/strsim_amd.h, ABI 1.5): 32 one-launch calls in flight, the 33rd has to retire them inside
+    strsim_pairs_device and one of those retirements fails (fault injection: STRSIM_FAULT_RETIRE_AT, read at context creation).
+    The 33rd call gets status 8 with the earlier call's message inside its own, was NOT enqueued (its output buffer is
+    untouched, no operation was counted), the calls retired before the fault are right, and the context goes on working."""
+    import torch
+    frames = {k: _mixed_frame(S, k) for k in (0, 40)}
+    exp = {k: O.batch_strings("levenshtein", f[0], f[1], 8) for k, f in frames.items()}
+    monkeypatch.setenv("STRSIM_FAULT_RETIRE_AT", "5")
+    with S.Context(0, one_launch=True) as ctx:
+        monkeypatch.delenv("STRSIM_FAULT_RETIRE_AT")  # (read once, at creation)
+        outs = [ctx.pairs_device("levenshtein", *frames[0][2]) for _ in range(32)]
+        sentinel = torch.full((len(frames[0][0]),), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ops = ctx.enqueued_ops
+        with pytest.raises(S.StrsimError) as ei:
+            ctx.pairs_device("levenshtein", *frames[0][2], out=sentinel)
+        assert ei.value.code == 8 and S.STATUS[8] == "ERR_EARLIER_CALL"
+        assert "retiring earlier pending calls" in ei.value.message and "not enqueued" in ei.value.message
+        assert "fault injected at retirement 5" in ei.value.message  # the earlier call's own message travels inside
+        assert ctx.enqueued_ops == ops
+        ctx.synchronize()  # nothing is pending any more: the failed drain retired (dropped) every slot
+        torch.cuda.synchronize()
+        assert bool((sentinel == -7.0).all())
+        for k in range(4):  # retired before the fault; (clean frames: the lane kernel finished every row of the others too)
+            assert_bit_exact(outs[k].cpu().numpy(), exp[0], frames[0][0], frames[0][1], "before the fault, call %d" % k)
+        # the context is usable: a frame with slow rows and a clean one, both modes of enqueueing
+        for k in (40, 0, 0, 40):
+            out = ctx.pairs_device("levenshtein", *frames[k][2])
+            ctx.synchronize()
+            assert_bit_exact(out.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "after the fault, %d slow rows" % k)
+
+
+def test_failed_retirement_is_reported_by_synchronize_itself(S, monkeypatch):
+    """The same fault outside a wrap is the retiring call's own error (STRSIM_ERR_INTERNAL from strsim_ctx_synchronize /
+    strsim_ctx_retire_oldest), every slot is released, and the context goes on working."""
+    frames = {k: _mixed_frame(S, k) for k in (0, 40)}
+    exp = {k: O.batch_strings("jaccard", f[0], f[1], 8) for k, f in frames.items()}
+    monkeypatch.setenv("STRSIM_FAULT_RETIRE_AT", "2")
+    with S.Context(0, one_launch=True) as ctx:
+        for _ in range(3):
+            ctx.pairs_device("jaccard", *frames[0][2])
+        with pytest.raises(S.StrsimError) as ei:
+            ctx.synchronize()
+        assert ei.value.code == 7 and "fault injected at retirement 2" in ei.value.message
+        ctx.synchronize()  # nothing left
+        for k in (40, 0):
+            out = ctx.pairs_device("jaccard", *frames[k][2])
+            ctx.synchronize()
+            assert_bit_exact(out.cpu().numpy(), exp[k], frames[k][0], frames[k][1], "after the fault, %d slow rows" % k)
 
 
 def test_pipelined_caller_with_early_copies_and_retire_oldest(S):

@@ -27,6 +27,8 @@ KNOBS = [
     {"POLARS_STRSIM_VIEWS": "1"},
     {"POLARS_STRSIM_TRACE": "1"},
     {"POLARS_STRSIM_DEVICE": "0"},
+    {"POLARS_STRSIM_STAGING_BUDGET_MB": "1"},   # (smaller than one call: every call's staging is released when it returns)
+    {"POLARS_STRSIM_STAGING_BUDGET_MB": "0"},   # (no budget)
     {"POLARS_STRSIM_DEVICES": "0,0", "POLARS_STRSIM_MIN_ROWS_PER_DEVICE": "20000"},
     {"POLARS_STRSIM_SINGLE_SLICE_ROWS": "1000", "POLARS_STRSIM_RAMP_ROWS": "8192", "POLARS_STRSIM_RAMP_GROW_PCT": "110", "POLARS_STRSIM_SLICE_ROWS": "30000"},
     {"POLARS_STRSIM_SINGLE_SLICE_ROWS": "1000", "POLARS_STRSIM_RAMP_ROWS": "70000", "POLARS_STRSIM_RAMP_GROW_PCT": "400"},
@@ -40,6 +42,8 @@ KNOBS = [
     {"STRSIM_LEV_WAVES_PER_CU": "64"},
     {"STRSIM_HUGE_WAVES_PER_CU": "1"},
     {"STRSIM_HUGE_WAVES_PER_CU": "32"},
+    {"STRSIM_RCCL_LIB": "/nonexistent/librccl.so"},  # (read by the C ABI's gather only -- tests/test_gather_abi.py runs it for real; here: no effect on a process that never gathers)
+    {"STRSIM_FAULT_RETIRE_AT": "1000000000"},  # (fault injection, armed but never reached here; the fault itself: tests/test_gpu_parity.py)
 ]
 
 
