@@ -368,22 +368,6 @@ def main():
     # Preheat (disclosed in the JSON line): the first 25-40 ms after the GPU goes from idle to this load run ~5-10 % slower
     # (clock ramp), which a short run (--warmup 5 --steps 20 is 35 ms) would measure instead of the steady state a 100 M-row
     # job is in.  One step is timed to size the preheat; every rank runs the same number of steps (the gather is collective).
-    # What ONE call costs a caller who does not loop: the very first call of the context -- workspace
-    # allocation, code-object load, idle clocks -- and a call on a GPU that has been idle for a second with everything warm.
-    # Wall clock around step + drain on this rank (at N > 1 the step includes its gather).  Untimed as far as `value` goes.
-    cold_first_call_ms = idle_gpu_call_ms = None
-    if not a.no_extra_modes:
-        torch.cuda.synchronize()
-        time.sleep(1.0)
-        t0 = time.perf_counter()
-        step(0)
-        drain()
-        cold_first_call_ms = (time.perf_counter() - t0) * 1e3
-        time.sleep(1.0)
-        t0 = time.perf_counter()
-        step(1)
-        drain()
-        idle_gpu_call_ms = (time.perf_counter() - t0) * 1e3
     preheat_steps = 0
     if a.preheat_ms > 0:
         step(0)
@@ -475,6 +459,36 @@ def main():
                         "enqueued_kernels_and_copies_per_step": (ctx.enqueued_ops - ops0) / max(a.steps, 1),
                         "call_mode": "stream_ordered (ABI default)", "steps": a.steps, "warmup": min(a.warmup, 5)}
         ctx.set_stream_ordered(False)
+
+    # What ONE call costs a caller who does not loop, measured AFTER everything else so that the idle seconds do not
+    # reach into the headline (two 1 s sleeps in front of the preheat cost it 0.7 %, profiles/r6_bench_lines.jsonl): (a) the first call of
+    # a NEW context on a GPU that has been idle for a second -- its workspace allocations and idle clocks; the code object is already
+    # loaded by then -- and (b) a call of the warm context after another idle second.  Wall clock around the call(s) of one pass over
+    # this rank's shard + synchronize, no gather.
+    cold_first_call_ms = idle_gpu_call_ms = None
+    if not a.no_extra_modes:
+        def one_pass(c):
+            os_ = out[:len(measures)]
+            for r0, r1, oa, va, ob, vb in parts:
+                if fused:
+                    c.pairs_device_all(oa, va, ob, vb, outs=[o[r0:r1] for o in os_])
+                else:
+                    for m, o in zip(measures, os_):
+                        c.pairs_device(m, oa, va, ob, vb, out=o[r0:r1])
+            c.synchronize()
+        drain()
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        cold_stream = torch.cuda.Stream()
+        with S.Context(local_rank, stream=cold_stream.cuda_stream) as cold_ctx:
+            one_pass(cold_ctx)
+            cold_first_call_ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        one_pass(ctx)
+        idle_gpu_call_ms = (time.perf_counter() - t0) * 1e3
 
     res = None
     if rank == 0:

@@ -36,6 +36,11 @@ static_assert(WIDE_LIST >= WIDE_ROWS && WIDE_BLOCK * 64 <= 65536, "one span alwa
 constexpr int U8_SPAN = 32;                  // ... of k_lane_utf8 (its symbol columns take the LDS: a larger span costs a workgroup per CU)
 constexpr int U8_ROWS = U8_SPAN * 64;        // 2048 rows
 constexpr int WIDE_MAXW = 4;
+#ifndef STRSIM_WIDE_ONE_WORD
+// 1: k_lane_wide also takes flagged ASCII rows whose LONGER string is <= 32 bytes (masks of one word) -- the rows k_lane_stage's LONG
+// geometry leaves behind under STRSIM_STAGE_LONG_TEXT_MAX, and short rows a staging overflow left in the mask.  Round 6's experiment.
+#define STRSIM_WIDE_ONE_WORD 0
+#endif
 
 // NDW dwords of vals[start, start + 4*NDW); bytes outside [0, total) read as 0.  start may be negative.
 template <int NDW>
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
         auto row_key = [&](uint32_t i, uint32_t la8, uint32_t lb8) -> uint32_t { // 0xFFFF: not a candidate
             if (!((s_mask[i >> 6] >> (i & 63u)) & 1ull)) return 0xFFFFu;
             const uint32_t mx = la8 > lb8 ? la8 : lb8, mn = la8 < lb8 ? la8 : lb8;
-            if (!(mx > 32u && mx <= 128u && mn >= 1u)) return 0xFFFFu;
+            if (!(mx > (STRSIM_WIDE_ONE_WORD ? 0u : 32u) && mx <= 128u && mn >= 1u)) return 0xFFFFu;
             const uint32_t steps = mn, pat = mx; // text = the shorter string, pattern = the longer one
             const uint32_t cls = (pat - 1u) >> 5; // masks of cls + 1 words: as wide as the PATTERN is long
             return (cls * 32u + ((steps - 1u) >> 2)) * 4u + (pat - 1u - 32u * cls) / 8u;
@@ -570,6 +575,7 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
                 const uint32_t fT = swap ? firstB : firstA, fP = swap ? firstA : firstB; // (the columns' first bytes: offsets[0])
                 const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
+                const bool pat2 = !STRSIM_WIDE_ONE_WORD || __ballot(has && lp > 32u) != 0ull;
                 const bool pat3 = __ballot(has && lp > 64u) != 0ull;
                 const bool pat4 = __ballot(has && lp > 96u) != 0ull;
                 const uint32_t wtw = 1u + (__ballot(has && lt > 32u) != 0ull) + (__ballot(has && lt > 64u) != 0ull) +
@@ -577,7 +583,11 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 bool done = false;
                 double res = 0.0;
                 const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
-                if (!pat3) // (the pattern is the longer string: two words or more)
+                if (!pat2) { // (only with STRSIM_WIDE_ONE_WORD: a round whose longest pattern fits one word)
+#if STRSIM_WIDE_ONE_WORD
+                    wide_round<MEASURE, 1>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+#endif
+                } else if (!pat3) // (the pattern is the longer string: two words or more)
                     wide_round<MEASURE, 2>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
                 else if (!pat4)
                     wide_round<MEASURE, 3>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);

@@ -49,6 +49,9 @@ struct OutPtrs {
 };
 
 #include "strsim_lane_stage.h"
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_PC)
+#include "strsim_lane_stage_pc.h" // lab only: the producer / consumer form of k_lane_stage (round 6's experiment)
+#endif
 #include "strsim_lane_lit.h"
 
 #include "strsim_kernel_wide.h"
@@ -122,6 +125,14 @@ static void launch_lane_t(const LaunchArgs &a)
             hipLaunchKernelGGL((k_lane_stage<M, T, L>), dim3((unsigned)gs), dim3(STAGE_BLOCK), 0, a.stream, a.offA, a.valA, a.rowsA,
                                a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
         };
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_PC)
+        if (((STRSIM_STAGE_PC >> M) & 1) != 0 && a.rowsA != 1 && a.rowsB != 1 && !a.long_rows) {
+            const uint64_t cus = (uint64_t)a.stage_grid / (uint64_t)STRSIM_STAGE_WAVES_PER_EU;
+            const uint64_t gs = stage_launch_size(nsb, cus * (uint64_t)STRSIM_PC_WG_PER_CU, cus);
+            hipLaunchKernelGGL((k_lane_stage_pc<M, STRSIM_PC_LUT != 0>), dim3((unsigned)gs), dim3(PC_THREADS), 0, a.stream, a.offA, a.valA, a.rowsA,
+                               a.offB, a.valB, a.rowsB, op, a.n, a.slowmask, a.status, a.qtab, a.sched, a.publish_host, a.publish_ticket);
+        } else
+#endif
         if (a.long_rows) go(std::false_type{}, std::true_type{});
         else if constexpr (stage_uses_lut<M>()) go(std::true_type{}, std::false_type{});
         else go(std::false_type{}, std::false_type{});

@@ -51,6 +51,12 @@
 #ifndef STRSIM_JARO_KEEP_EQ_FILLS
 #define STRSIM_JARO_KEEP_EQ_FILLS 1 // the bit-fill form of Jaro's cores (the long-row geometry) keeps the first pass's masks for the zip pass too
 #endif
+#ifndef STRSIM_STAGE_LONG_TEXT_MAX
+// LONG geometry only (frames of long rows, cfg3): rows whose SHORTER string exceeds this many bytes are left to k_lane_wide's one-word
+// class (STRSIM_WIDE_ONE_WORD).  32 = off.  Round 6's experiment: a block's critical path is its longest round,
+// and on Zipf lengths the 64 longest of ~275 texts run 32 columns where the next round runs 14 (LAB 3.3 [r5]).
+#define STRSIM_STAGE_LONG_TEXT_MAX 32
+#endif
 #ifndef STRSIM_STAGE_RANGE_MAX
 #define STRSIM_STAGE_RANGE_MAX 64   // chunks of 64 rows a workgroup takes from the device-wide counter at a time, at most
 #endif
@@ -650,7 +656,8 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 const uint32_t lb8 = bcastB ? litBlen : s_off[1][i + 1u] - s_off[1][i];
                 // mine: both strings <= 32 bytes and inside what was copied to the staging areas (the literal has its own copy)
                 const bool stA = bcastA || misA + a0 + la8 <= stagedA, stB = bcastB || misB + b0 + lb8 <= stagedB;
-                const bool mine = have && la8 <= 32u && lb8 <= 32u && stA && stB;
+                bool mine = have && la8 <= 32u && lb8 <= 32u && stA && stB;
+                if (LONG && STRSIM_STAGE_LONG_TEXT_MAX < 32 && !bcastA && !bcastB) mine = mine && (la8 < lb8 ? la8 : lb8) <= (uint32_t)STRSIM_STAGE_LONG_TEXT_MAX;
                 const uint32_t wa = bcastA ? LIT : misA + a0, wb = bcastB ? LIT + 32u : COLB + misB + b0;
                 const bool swap = !bcastA && !bcastB && la8 > lb8; // the columns walk the shorter string (every measure is symmetric: strsim_lane_core.h)
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;

@@ -88,6 +88,46 @@ def test_windows_match_the_oracle(frame, measure):
         assert bad.size == 0, (measure, s, int(bad[0]), got[bad[0]], exp[bad[0]])
 
 
+def _cores():
+    n = os.cpu_count() or 1
+    try:  # (the GPU boxes: a cgroup quota of 16 CPUs on 256 logical ones -- more threads than that only get throttled)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(round(int(q) / int(per)))))
+    except Exception:
+        pass
+    return min(n, 32)
+
+
+def _every_row_against_the_oracle(measure, parts, out, chunk=8_000_000):
+    """EVERY row of a frame against the oracle (full-size parity was by windows).  The oracle reads the very bytes
+    the kernels read -- the device columns copied to the host, `chunk` rows at a time -- so generator and transfer cannot hide a
+    difference; that the device generator equals the host one is what the window tests (host-generated) hold."""
+    cores, bad_total, rows_total = _cores(), 0, 0
+    for r0, r1, oa, va, ob, vb in parts:
+        n = r1 - r0
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            ha = oa[c0:c1 + 1].cpu().numpy().view(np.uint32)
+            hb = ob[c0:c1 + 1].cpu().numpy().view(np.uint32)
+            hva = va[int(ha[0]):int(ha[-1])].cpu().numpy()
+            hvb = vb[int(hb[0]):int(hb[-1])].cpu().numpy()
+            exp = O.batch(measure, ha - ha[0], hva, hb - hb[0], hvb, nthreads=cores)
+            got = out[r0 + c0:r0 + c1].cpu().numpy()
+            bad = np.nonzero(got.view(np.uint64) != exp.view(np.uint64))[0]
+            assert bad.size == 0, (measure, r0 + c0 + int(bad[0]), got[bad[0]], exp[bad[0]], int(bad.size))
+            rows_total += c1 - c0
+    return rows_total
+
+
+@pytest.mark.parametrize("measure", O.MEASURES)
+def test_every_row_of_cfg2_matches_the_oracle(frame, measure):
+    """cfg2 at full size, all 100 M rows, bit for bit, for each of the five measures."""
+    offA, valA, offB, valB = frame["cols"]
+    x = run(frame, measure)
+    assert _every_row_against_the_oracle(measure, [(0, ROWS, offA, valA, offB, valB)], x) == ROWS
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The other BASELINE.json configs at their full size, on the frames bench.py times (bench_support/workload.py):
 # cfg3 (Jaro-Winkler, 100 M rows, Zipf 4..128 bytes), cfg5 (Levenshtein, 10 M rows, U{1..1024} bytes, held as two row
@@ -153,6 +193,8 @@ def test_config_frame_full_size(name, rows, win, nwin):
         if measure == "levenshtein":
             assert t.equal(x.view(t.int64), run(swap=True).view(t.int64))     # distance is symmetric
         _oracle_windows(measure, cfg, rows, x, win, nwin)
+        if name == "cfg3":  # (cfg5's 2.6e12 DP cells are hours of oracle time: windows there)
+            assert _every_row_against_the_oracle(measure, parts, x) == rows
 
 
 def test_cfg4_fused_five_outputs_full_size():
