@@ -234,8 +234,14 @@ struct PipeSet {
     uint64_t last_used = 0; // the pool's clock when the set came back
     Pipe &at(size_t i) { while (p.size() <= i) p.push_back(new Pipe); return *p[i]; }
     uint64_t live() const { uint64_t b = 0; for (const Pipe *q : p) b += q->live(); return b; }
-    void close() { for (Pipe *q : p) q->close(); }
-    ~PipeSet() { for (Pipe *q : p) delete q; }
+    void close()
+    {   // (releasing a pipeline selects its device: put the calling thread's own choice back)
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        for (Pipe *q : p) q->close();
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
+    ~PipeSet() { close(); for (Pipe *q : p) delete q; }
 };
 
 // The staging of ALL calling threads against ONE budget (round 5 kept a set per calling thread, grow-only, for

@@ -300,9 +300,37 @@ __device__ __forceinline__ void wide_text(const uint8_t *__restrict__ valA, uint
     a0w = ta[0];
 }
 
+#ifndef STRSIM_WIDE_PREFETCH
+// 1: the windows of the NEXT two-word round are fetched into registers before the cores of the current two-word round run (rows two
+// rounds ahead, windows one): round 6's experiment (LAB_NOTES 9.0 "~4 % of cfg3").  See profiles/r6_rounds_ab.txt.
+#define STRSIM_WIDE_PREFETCH 0
+#endif
+// a two-word round's windows in flight: 4 x 16-byte pieces of pattern per row (coop_fetch<4>), 2 or 4 of text
+struct WidePref {
+    bool valid;
+    uint4 vp[4], vt[4];
+};
+__device__ __forceinline__ void wide_prefetch2(const uint8_t *vT, const uint8_t *vP, uint32_t tstart, uint32_t pstart, uint32_t wtw, WidePref &pf
+                                               STRSIM_COOP_RANGES)
+{
+    uint32_t lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    coop_fetch<4>(vP, pstart, lane, pf.vp STRSIM_COOP_RANGES_ARG);
+    if (STRSIM_WIDE_PREFETCH == 2) { // (the pattern alone: 16 registers instead of 32; the text is fetched when its round starts)
+    } else if (wtw <= 1u) {
+        uint4 t[2];
+        coop_fetch<2>(vT, tstart, lane, t STRSIM_COOP_RANGES_ARG);
+        pf.vt[0] = t[0]; pf.vt[1] = t[1];
+    } else {
+        coop_fetch<4>(vT, tstart, lane, pf.vt STRSIM_COOP_RANGES_ARG);
+    }
+    pf.valid = true;
+}
+
 // W: words of the masks (by the round's longest PATTERN), wtw: 32-byte units of text to fetch (uniform, 1..4)
+// pf: the round's windows, already fetched (two-word rounds under STRSIM_WIDE_PREFETCH; valid implies the round is not an edge round)
 template <int MEASURE, int W>
-__device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uint32_t totalA,
+__device__ __forceinline__ void wide_round(const WidePref &pf, const uint8_t *__restrict__ valA, uint32_t totalA,
                                            const uint8_t *__restrict__ valB, uint32_t totalB, uint32_t firstA, uint32_t firstB, bool has, uint32_t a0,
                                            uint32_t la, uint32_t b0, uint32_t lb, uint32_t wtw, const LdsTxt &txt, bool &done, double &res WIDE_STAMP_PARAMS
                                            STRSIM_COOP_RANGES)
@@ -329,12 +357,23 @@ __device__ __forceinline__ void wide_round(const uint8_t *__restrict__ valA, uin
     if (!edge) {
         // both fetches in flight together; the pattern passes through the rows first, then the text moves in
         const uint32_t pstart = has ? b0 : firstB, tstart = has ? a0 : firstA;
+        const bool have = W == 2 && STRSIM_WIDE_PREFETCH && pf.valid; // (uniform)
         uint4 vp[CoopGeom<2 * W>::ITER];
-        coop_fetch<2 * W>(valB, pstart, lane, vp STRSIM_COOP_RANGES_ARG);
+        if (have) {
+#pragma unroll
+            for (int q = 0; q < CoopGeom<2 * W>::ITER; ++q) vp[q] = pf.vp[q & 3];
+        } else {
+            coop_fetch<2 * W>(valB, pstart, lane, vp STRSIM_COOP_RANGES_ARG);
+        }
         auto text = [&](auto wt) {
             constexpr int WT = decltype(wt)::value;
             uint4 vt[CoopGeom<2 * WT>::ITER];
-            coop_fetch<2 * WT>(valA, tstart, lane, vt STRSIM_COOP_RANGES_ARG);
+            if (have && WT <= 2 && STRSIM_WIDE_PREFETCH == 1) {
+#pragma unroll
+                for (int q = 0; q < CoopGeom<2 * WT>::ITER; ++q) vt[q] = pf.vt[q & 3];
+            } else {
+                coop_fetch<2 * WT>(valA, tstart, lane, vt STRSIM_COOP_RANGES_ARG);
+            }
             coop_store_groups<2 * W>(base, lane, vp);
             wide_pattern_regs<W>(base, lane, wp);
             coop_store_text<2 * WT>(base, lane, vt);
@@ -559,50 +598,99 @@ __global__ __launch_bounds__(WIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(STRS
                 return q;
             };
             WIDE_STAMP(0);
-            Rows cur = take();
-            while (cur.valid) {
-                const Rows nxt = take();
-#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                wst_acc[6] += 1;
-#endif
-                WIDE_STAMP(1);
-                const bool has = cur.has;
-                const uint32_t i = cur.i, a0 = cur.a0, la = cur.la, b0 = cur.b0, lb = cur.lb;
+            // what a round's lanes fetch and how wide its masks are (uniform ballots over the round's rows)
+            struct Cls {
+                const uint8_t *vT, *vP; uint32_t tT, tP, fT, fP, t0, lt, p0, lp, wtw; bool pat2, pat3, pat4;
+            };
+            auto classify = [&](const Rows &q) -> Cls {
+                Cls c;
+                const bool swap = q.la > q.lb; // the columns walk the shorter string
+                c.vT = swap ? valB : valA; c.vP = swap ? valA : valB;
+                c.tT = swap ? totalB : totalA; c.tP = swap ? totalA : totalB;
+                c.fT = swap ? firstB : firstA; c.fP = swap ? firstA : firstB; // (the columns' first bytes: offsets[0])
+                c.t0 = swap ? q.b0 : q.a0; c.lt = swap ? q.lb : q.la; c.p0 = swap ? q.a0 : q.b0; c.lp = swap ? q.la : q.lb;
+                c.pat2 = !STRSIM_WIDE_ONE_WORD || __ballot(q.has && c.lp > 32u) != 0ull;
+                c.pat3 = __ballot(q.has && c.lp > 64u) != 0ull;
+                c.pat4 = __ballot(q.has && c.lp > 96u) != 0ull;
+                c.wtw = 1u + (__ballot(q.has && c.lt > 32u) != 0ull) + (__ballot(q.has && c.lt > 64u) != 0ull) + (__ballot(q.has && c.lt > 96u) != 0ull);
+                return c;
+            };
+            const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
+            auto finish = [&](uint32_t i, bool done, double res) {
                 const uint64_t row = cw0 * 64u + i;
-                const bool swap = la > lb; // the columns walk the shorter string
-                const uint8_t *vT = swap ? valB : valA, *vP = swap ? valA : valB;
-                const uint32_t tT = swap ? totalB : totalA, tP = swap ? totalA : totalB;
-                const uint32_t fT = swap ? firstB : firstA, fP = swap ? firstA : firstB; // (the columns' first bytes: offsets[0])
-                const uint32_t t0 = swap ? b0 : a0, lt = swap ? lb : la, p0 = swap ? a0 : b0, lp = swap ? la : lb;
-                const bool pat2 = !STRSIM_WIDE_ONE_WORD || __ballot(has && lp > 32u) != 0ull;
-                const bool pat3 = __ballot(has && lp > 64u) != 0ull;
-                const bool pat4 = __ballot(has && lp > 96u) != 0ull;
-                const uint32_t wtw = 1u + (__ballot(has && lt > 32u) != 0ull) + (__ballot(has && lt > 64u) != 0ull) +
-                                     (__ballot(has && lt > 96u) != 0ull);
-                bool done = false;
-                double res = 0.0;
-                const LdsTxt txt{STRSIM_LDS_ADDR(&s_txt[wv][0][0]) + lane * 128u, (lane & 31u) << 2};
-                if (!pat2) { // (only with STRSIM_WIDE_ONE_WORD: a round whose longest pattern fits one word)
-#if STRSIM_WIDE_ONE_WORD
-                    wide_round<MEASURE, 1>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
-#endif
-                } else if (!pat3) // (the pattern is the longer string: two words or more)
-                    wide_round<MEASURE, 2>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
-                else if (!pat4)
-                    wide_round<MEASURE, 3>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
-                else
-                    wide_round<MEASURE, 4>(vT, tT, vP, tP, fT, fP, has, t0, lt, p0, lp, wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
-                WIDE_STAMP(3);
                 if (done) {
                     STRSIM_CHECK_INDEX(K_WIDE, 30, row, row, n);
                     STRSIM_CHECK_INDEX(K_WIDE, 31, row, i >> 6, WIDE_BLOCK);
                     out[row] = res;
                     atomicAnd(&s_mask[i >> 6], ~(1ull << (i & 63u)));
                 }
+            };
+            WidePref none;
+            none.valid = false;
+            Rows cur = take();
+            // ---- loop A: every round (with STRSIM_WIDE_PREFETCH: the rounds of three- and four-word masks -- they come first, the list
+            //      is dealt from its long end -- and their registers leave no room for a deeper pipeline)
+            while (cur.valid) {
+                const Cls c = classify(cur);
+                if (STRSIM_WIDE_PREFETCH && !c.pat3) break; // two-word rounds (and narrower) from here on: loop B
+                const Rows nxt = take();
+#if defined(STRSIM_LAB) && defined(STRSIM_WIDE_STAMPS)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                wst_acc[6] += 1;
+#endif
+                WIDE_STAMP(1);
+                bool done = false;
+                double res = 0.0;
+                if (!c.pat2) { // (only with STRSIM_WIDE_ONE_WORD: a round whose longest pattern fits one word)
+#if STRSIM_WIDE_ONE_WORD
+                    wide_round<MEASURE, 1>(none, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+#endif
+                } else if (!c.pat3) // (the pattern is the longer string: two words or more)
+                    wide_round<MEASURE, 2>(none, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                else if (!c.pat4)
+                    wide_round<MEASURE, 3>(none, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                else
+                    wide_round<MEASURE, 4>(none, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                WIDE_STAMP(3);
+                finish(cur.i, done, res);
                 cur = nxt;
                 WIDE_STAMP(4);
             }
+#if STRSIM_WIDE_PREFETCH
+            // ---- loop B: the two-word rounds, one stage deeper: rows TWO rounds ahead, and the next round's windows go out into
+            //      registers before this round's cores run (they land under the cores instead of in front of the next round)
+            if (cur.valid) {
+                Rows nxt = take();
+                WidePref pf;
+                pf.valid = false;
+                while (cur.valid) {
+                    const Rows nn = nxt.valid ? take() : nxt;
+                    const Cls c = classify(cur);
+                    WidePref pn;
+                    pn.valid = false;
+                    if (nxt.valid) {
+                        const Cls cn = classify(nxt);
+                        const bool edge_n = __ballot((nxt.has && ((uint64_t)cn.p0 + 64u > cn.tP || (uint64_t)cn.t0 + 32u * cn.wtw > cn.tT)) ||
+                                                     cn.tP - cn.fP < 64u || cn.tT - cn.fT < 32u * cn.wtw) != 0ull;
+                        if (cn.pat2 && !edge_n)
+                            wide_prefetch2(cn.vT, cn.vP, nxt.has ? cn.t0 : cn.fT, nxt.has ? cn.p0 : cn.fP, cn.wtw, pn STRSIM_COOP_RANGES_ARG);
+                    }
+                    bool done = false;
+                    double res = 0.0;
+                    if (!c.pat2) {
+#if STRSIM_WIDE_ONE_WORD
+                        wide_round<MEASURE, 1>(none, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+#endif
+                    } else {
+                        wide_round<MEASURE, 2>(pf, c.vT, c.tT, c.vP, c.tP, c.fT, c.fP, cur.has, c.t0, c.lt, c.p0, c.lp, c.wtw, txt, done, res WIDE_STAMP_ARGS STRSIM_COOP_RANGES_ARG);
+                    }
+                    finish(cur.i, done, res);
+                    cur = nxt;
+                    nxt = nn;
+                    pf = pn;
+                }
+            }
+#endif
         }
         lds_barrier();
         WIDE_STAMP(5);
