@@ -104,6 +104,10 @@ POLARS_PLUGIN_DECLARE(sorensen_dice)
  * strsim.rs:78-84, :109-123).  out[0..7] = live pinned bytes, live device bytes, budget bytes (0 = none), pipeline sets, sets in use,
  * sets released so far, calls that had to wait for the budget, peak live bytes seen when a call returned. */
 POLARS_PLUGIN_API void _polars_plugin_strsim_staging_stats(uint64_t out[8]);
+/* Small calls of concurrent engine threads are combined into one launch when enough of them are in flight (csrc/plugin_pipeline.h:
+ * Combiner; POLARS_STRSIM_COALESCE / _COALESCE_MIN_INFLIGHT / _COALESCE_ROWS).  out[0..3] = combined launches, the calls they
+ * carried, the most calls in one launch, small calls that took the ordinary path. */
+POLARS_PLUGIN_API void _polars_plugin_strsim_coalesce_stats(uint64_t out[4]);
 /* Change the budget of a running process (tests; 0 = no budget).  Takes effect with the next call. */
 POLARS_PLUGIN_API void _polars_plugin_strsim_staging_set_budget_mb(uint64_t megabytes);
 

@@ -132,14 +132,23 @@ struct Buf {
         if (bytes <= cap) return;
         release();
         const size_t want = bytes + bytes / 4 + 4096;
+#ifdef STRSIM_TEST_HOOKS // (the test-hooks build runs the pool's and the combiner's logic without a device: plain host memory)
+        p = malloc(want);
+        if (!p) fail("out of host memory");
+#else
         if (device) HIP_OR_FAIL(hipMalloc(&p, want)); else HIP_OR_FAIL(hipHostMalloc(&p, want, hipHostMallocDefault));
+#endif
         cap = want;
         (device ? g_live_device : g_live_pinned).fetch_add(want, std::memory_order_relaxed);
     }
     void release()
     {
         if (p) {
+#ifdef STRSIM_TEST_HOOKS
+            free(p);
+#else
             if (device) (void)hipFree(p); else (void)hipHostFree(p);
+#endif
             (device ? g_live_device : g_live_pinned).fetch_sub(cap, std::memory_order_relaxed);
         }
         p = nullptr; cap = 0;
@@ -199,14 +208,15 @@ struct Pipe {
     uint64_t live() const { return slot[0].live() + slot[1].live() + slot[2].live() + lit_off.cap + lit_val.cap + lit_h_off.cap + lit_h_val.cap; }
     void close()
     {
-        if (!ctx) return;
-        (void)hipSetDevice(device);
-        if (d2h) (void)hipStreamDestroy(d2h);
-        d2h = nullptr;
+        if (ctx) {
+            (void)hipSetDevice(device);
+            if (d2h) (void)hipStreamDestroy(d2h);
+            d2h = nullptr;
+        }
         for (auto &s : slot) s.release();
         lit_off.release(); lit_val.release();
         lit_h_off.release(); lit_h_val.release();
-        strsim_ctx_destroy(ctx);
+        if (ctx) strsim_ctx_destroy(ctx);
         ctx = nullptr;
     }
     ~Pipe() { close(); }
@@ -230,7 +240,8 @@ struct Pipe {
 struct PipeSet {
     std::vector<Pipe *> p;
     bool in_use = false;
-    uint64_t reserved = 0;  // what the call that holds the set asked for (its estimate; the set's real size may be larger)
+    uint64_t reserved = 0;  // in use: max(what the call that holds the set asked for, what the set held when it was leased) -- written under
+                            // the pool's lock; the set itself belongs to its holder until it comes back and is not looked at by anybody else
     uint64_t last_used = 0; // the pool's clock when the set came back
     Pipe &at(size_t i) { while (p.size() <= i) p.push_back(new Pipe); return *p[i]; }
     uint64_t live() const { uint64_t b = 0; for (const Pipe *q : p) b += q->live(); return b; }
@@ -259,14 +270,21 @@ class StagingPool {
     PipeSet *lease(uint64_t need)
     {
         std::unique_lock<std::mutex> lk(m_);
+        bool waited = false;
         for (;;) {
             uint64_t in_use_bytes = 0, idle_bytes = 0;
             size_t running = 0;
             PipeSet *mru = nullptr;
             for (PipeSet *s : sets_) {
-                if (s->in_use) { in_use_bytes += std::max(s->reserved, s->live()); ++running; continue; }
+                // (a set in use is its holder's: its vectors and buffers change under the holder's hands -- only the figure written
+                //  under this lock is read here.  [r6] TSan found lease() walking a running call's set: tests/run_sanitizers.sh)
+                if (s->in_use) { in_use_bytes += s->reserved; ++running; continue; }
                 idle_bytes += s->live();
                 if (!mru || s->last_used > mru->last_used) mru = s;
+            }
+            {   // what the running calls have really allocated, from the global counters (atomic): whatever is alive and not idle
+                const uint64_t alive = g_live_pinned.load(std::memory_order_relaxed) + g_live_device.load(std::memory_order_relaxed);
+                if (alive > idle_bytes && alive - idle_bytes > in_use_bytes) in_use_bytes = alive - idle_bytes;
             }
             const uint64_t mine = mru ? std::max(need, mru->live()) : need;
             uint64_t others_idle = mru ? idle_bytes - mru->live() : 0;
@@ -283,10 +301,10 @@ class StagingPool {
                 PipeSet *s = mru;
                 if (!s) { s = new PipeSet; sets_.push_back(s); }
                 s->in_use = true;
-                s->reserved = need;
+                s->reserved = mine;
                 return s;
             }
-            ++waits_;
+            if (!waited) { waited = true; ++waits_; } // (calls that waited, not wake-ups)
             cv_.wait(lk); // a running call returns its set (give_back)
         }
     }

@@ -38,10 +38,12 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
 {
     const size_t D = devs.size();
     ptimes.assign(D, PipeTimes{});
-    // this call's pipelines, leased for its duration (StagingPool): the estimate is three slots of the largest slice the call will
-    // cut, ~64 bytes a row on either side of the link (offsets or lengths + ~17-byte strings twice + the f64 result, with the slack
-    // Buf::reserve adds) -- the pool counts a set at its real size as soon as that is larger
-    const uint64_t need = 2 * 3 * std::min<uint64_t>(n, SLICE_ROWS * D) * 64;
+    // this call's pipelines, leased for its duration (StagingPool).  The estimate: three slots of the largest slice the call will cut
+    // (the ramp and the taper keep it near 0.4 n below the 2 M-row steady state), ~96 bytes a row in a slot -- pinned: one length byte
+    // and ~17 bytes of string per column, the f64 result; device: the same, offsets, and the landing area of one-pass slices; with
+    // the slack Buf::reserve adds.  Measured: 411 MB after a 4 M-row call of cfg2's strings (this gives 461), ~0.55 GB after a 10 M-row
+    // one (576).  The pool counts a set at its real size as soon as that is larger, so a frame of long strings corrects it.
+    const uint64_t need = 3 * 96 * std::min<uint64_t>(std::max<uint64_t>(n * 2 / 5, 1), SLICE_ROWS * D);
     PipeLease lease(need);
     std::vector<Pipe *> pipes(D);
     std::vector<hipStream_t> streams(D);
@@ -281,6 +283,218 @@ void run_rows(int measure, const Column (&col)[2], const bool (&lit)[2], uint64_
     for (; finished < launched; ++finished) finish(finished % D, slot_of(finished));
     drain.armed = false;
 }
+
+// ---- small calls of CONCURRENT engine threads, combined into one launch ("batching of concurrent small calls") ----
+// An elementwise plugin is called per morsel / per group from the engine's own threads (polars_strsim/__init__.py:15), and a small
+// call is one kernel launch + one synchronise: 26 us alone, ~100 us each when 16 threads do it at once (160-195 K calls/s in all on a
+// box with a 16-CPU quota: bench_support/micro/plugin_small_threads.cpp).  With POLARS_STRSIM_COALESCE=1, when enough small calls are
+// in flight (POLARS_STRSIM_COALESCE_MIN_INFLIGHT, default 8) they are combined, group-commit style: a call joins the OPEN batch of its
+// measure -- or opens one and becomes its leader -- reserves its rows and bytes there, packs them into the batch's pinned arena (the
+// offsets of one batch are ONE column: every member's rows start where the previous member's end), and waits; the leader waits for the
+// combined launch in front of it to finish (calls keep joining meanwhile), seals the batch, waits for its members to finish packing,
+// launches ONE kernel over all rows, synchronises, and releases the members, who copy their rows out.  Every wait spins for up to
+// 200 us before it sleeps (a futex wake-up costs more than the launch: with condition variables alone the combiner ran at HALF the
+// ordinary path's rate).  Columns only (a literal side takes the ordinary path), one device.
+// OPT-IN, by its own measurement (profiles/r6_small_calls.txt): 6 calls share a launch at 16 threads and the rate is +5..15 % there,
+// -34 % at 8 threads, equal at 32 -- what saturates at ~160 K calls/s is the box's CPU quota under threads that spin in the runtime,
+// not the launch path, and a combiner cannot give CPUs back that its own members spin on.
+// POLARS_STRSIM_COALESCE_ROWS: the largest call that may join (default 8192 rows).
+constexpr uint64_t COMBO_ROWS = 65536, COMBO_BYTES = (uint64_t)2 << 20; // a batch's capacity: rows, packed bytes per column
+
+struct ComboBatch {
+    int measure = 0;
+    Buf h_off[2], h_val[2], h_out; // pinned, fixed capacity (members pack concurrently: nothing may move)
+    uint64_t rows = 0, bytes[2] = {0, 0};
+    int members = 0, inside = 0;
+    std::atomic<int> packed{0};     // (the waits below spin on these before they sleep: a futex wake-up costs more than the launch)
+    std::atomic<bool> done{false};
+    bool sealed = false, failed = false;
+    std::string err;
+    void reset(int m)
+    {
+        measure = m; rows = 0; bytes[0] = bytes[1] = 0; members = inside = 0;
+        packed.store(0, std::memory_order_relaxed); done.store(false, std::memory_order_relaxed);
+        sealed = failed = false; err.clear();
+        for (int s = 0; s < 2; ++s) {
+            h_off[s].reserve((COMBO_ROWS + 1) * sizeof(uint32_t));
+            h_val[s].reserve(COMBO_BYTES + 4096);
+            static_cast<uint32_t *>(h_off[s].p)[0] = 0u;
+        }
+        h_out.reserve(COMBO_ROWS * sizeof(double));
+    }
+};
+
+std::atomic<int> g_small_inflight{0}; // small (direct) plugin calls inside the library right now, combined or not
+struct SmallCallGuard {
+    int before;
+    SmallCallGuard() : before(g_small_inflight.fetch_add(1, std::memory_order_relaxed)) {}
+    ~SmallCallGuard() { g_small_inflight.fetch_sub(1, std::memory_order_relaxed); }
+};
+
+class Combiner {
+  public:
+    // true: the call was computed as a member of a combined launch (out[0 .. n) is filled); false: not eligible, take the ordinary path
+    bool run(int measure, const Column (&col)[2], uint64_t n, double *out, int device)
+    {
+        const uint64_t need[2] = {range_bytes(col[0], 0, n), range_bytes(col[1], 0, n)};
+        if (need[0] > COMBO_BYTES / 4 || need[1] > COMBO_BYTES / 4) return false; // (a call of long strings: its own launch)
+        ComboBatch *b;
+        bool leader = false;
+        uint64_t row0, base[2];
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            b = open_[measure];
+            if (!b || b->sealed || b->rows + n > COMBO_ROWS || b->bytes[0] + need[0] > COMBO_BYTES || b->bytes[1] + need[1] > COMBO_BYTES) {
+                // (a full batch stays with its leader, who seals it; this call opens the next one)
+                if (free_.empty()) {
+                    b = new ComboBatch;
+                } else {
+                    b = free_.back();
+                    free_.pop_back();
+                }
+                b->reset(measure); // (first use: pins the arenas -- under the lock, once per batch object; a handful exist)
+                open_[measure] = b;
+                leader = true;
+            }
+            row0 = b->rows; base[0] = b->bytes[0]; base[1] = b->bytes[1];
+            b->rows += n; b->bytes[0] += need[0]; b->bytes[1] += need[1];
+            b->members++; b->inside++;
+        }
+        // pack this call's rows into the batch's column: offsets continue the previous member's
+        std::string my_err;
+        for (int s = 0; s < 2; ++s) {
+            uint32_t *off = static_cast<uint32_t *>(b->h_off[s].p) + row0;
+            try {
+                pack_range(col[s], 0, n, off, base[s], base[s] + need[s], static_cast<uint8_t *>(b->h_val[s].p));
+            } catch (const PluginError &e) { // (a malformed view: this call fails -- below -- the batch goes on; keep its offsets monotone)
+                if (my_err.empty()) my_err = e.msg;
+                for (uint64_t i = 1; i <= n; ++i) off[i] = (uint32_t)(base[s] + need[s]);
+            }
+        }
+        std::string batch_err;
+        b->packed.fetch_add(1, std::memory_order_acq_rel);
+        {
+            std::unique_lock<std::mutex> lk(m_, std::defer_lock);
+            if (leader) {
+                // group commit: calls keep joining while the launch in front runs
+                spin_until([&] { return !launch_in_flight_.load(std::memory_order_acquire); });
+                lk.lock();
+                cv_.wait(lk, [&] { return !launch_in_flight_.load(std::memory_order_acquire); });
+                b->sealed = true;
+                if (open_[measure] == b) open_[measure] = nullptr;
+                launch_in_flight_.store(true, std::memory_order_release);
+                const int members = b->members; // (final: the batch is sealed)
+                const uint64_t rows = b->rows;
+                lk.unlock();
+                if (!spin_until([&] { return b->packed.load(std::memory_order_acquire) == members; })) {
+                    lk.lock();
+                    cv_.wait(lk, [&] { return b->packed.load(std::memory_order_acquire) == members; });
+                    lk.unlock();
+                }
+                std::string err;
+                try {
+#ifdef STRSIM_TEST_HOOKS
+                    if (test_launch) { // (the test-hooks build: a CPU stand-in for the kernel, so that the protocol runs under the sanitizers)
+                        test_launch(static_cast<const uint32_t *>(b->h_off[0].p), static_cast<const uint8_t *>(b->h_val[0].p),
+                                    static_cast<const uint32_t *>(b->h_off[1].p), static_cast<const uint8_t *>(b->h_val[1].p), rows,
+                                    static_cast<double *>(b->h_out.p));
+                        throw 0;
+                    }
+#endif
+                    PipeLease lease(3 * 96 * rows);
+                    Pipe &P = lease.set->at(0);
+                    strsim_ctx_t *ctx = P.open(device);
+                    if (strsim_pairs_device_small(ctx, measure, static_cast<const uint32_t *>(mapped(b->h_off[0].p)), static_cast<const uint8_t *>(mapped(b->h_val[0].p)), rows,
+                                                  static_cast<const uint32_t *>(mapped(b->h_off[1].p)), static_cast<const uint8_t *>(mapped(b->h_val[1].p)), rows,
+                                                  static_cast<double *>(mapped(b->h_out.p)), rows) != STRSIM_OK ||
+                        strsim_ctx_synchronize(ctx) != STRSIM_OK)
+                        err = strsim_last_error_message();
+                } catch (const PluginError &e) {
+                    err = e.msg;
+#ifdef STRSIM_TEST_HOOKS
+                } catch (int) { // (the stand-in ran)
+#endif
+                } catch (...) {
+                    err = "unexpected failure in a combined launch";
+                }
+                lk.lock();
+                b->failed = !err.empty();
+                b->err = err;
+                launch_in_flight_.store(false, std::memory_order_release);
+                b->done.store(true, std::memory_order_release);
+                ++batches_;
+                combined_ += (uint64_t)b->members;
+                if ((uint64_t)b->members > max_members_) max_members_ = (uint64_t)b->members;
+                cv_.notify_all();
+            } else {
+                if (!spin_until([&] { return b->done.load(std::memory_order_acquire); })) {
+                    lk.lock();
+                    cv_.notify_all(); // (a leader asleep on `packed` sees this member's count)
+                    cv_.wait(lk, [&] { return b->done.load(std::memory_order_acquire); });
+                    lk.unlock();
+                }
+                lk.lock();
+            }
+            if (b->failed) batch_err = b->err;
+        }
+        if (batch_err.empty() && my_err.empty()) memcpy(out, static_cast<const double *>(b->h_out.p) + row0, n * sizeof(double));
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (--b->inside == 0) free_.push_back(b);
+        }
+        if (!my_err.empty()) fail(my_err);
+        if (!batch_err.empty()) fail(batch_err);
+        return true;
+    }
+    // out[0..3] = combined launches, calls they carried, most calls in one launch, small calls that took the ordinary path
+    void stats(uint64_t *out)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        out[0] = batches_; out[1] = combined_; out[2] = max_members_; out[3] = direct_.load(std::memory_order_relaxed);
+    }
+    std::atomic<uint64_t> direct_{0};
+#ifdef STRSIM_TEST_HOOKS
+    void (*test_launch)(const uint32_t *, const uint8_t *, const uint32_t *, const uint8_t *, uint64_t, double *) = nullptr;
+#endif
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    ComboBatch *open_[STRSIM_NUM_MEASURES] = {};
+    std::vector<ComboBatch *> free_;
+    std::atomic<bool> launch_in_flight_{false};
+    uint64_t batches_ = 0, combined_ = 0, max_members_ = 0;
+    // spin on `pred` for up to ~200 us (a combined launch is ~30 us); false: not yet -- the caller sleeps on the condition variable
+    template <class Pred> static bool spin_until(Pred pred)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (pred()) return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) return pred();
+        }
+    }
+};
+// (never destroyed, like the staging pool: pinned memory and a static destructor do not mix)
+Combiner &combiner() { static Combiner *c = new Combiner; return *c; }
+
+struct CoalesceKnobs {
+    bool on;
+    int min_inflight;
+    uint64_t rows;
+    CoalesceKnobs()
+    {
+        const char *e = getenv("POLARS_STRSIM_COALESCE");
+        on = e && atoi(e) != 0; // (opt-in: see above)
+        const char *m = getenv("POLARS_STRSIM_COALESCE_MIN_INFLIGHT");
+        min_inflight = m && atoi(m) >= 1 ? atoi(m) : 8;
+        rows = env_rows("POLARS_STRSIM_COALESCE_ROWS", 8192);
+        if (rows > COMBO_ROWS / 2) rows = COMBO_ROWS / 2;
+    }
+};
+const CoalesceKnobs &coalesce_knobs() { static const CoalesceKnobs k; return k; }
 
 // ---- output validity: AND of the input validities, built word by word on the packing pool ---------------------------
 // bits [bit0, bit0 + n) of `src` (LSB-first, Arrow) as 64-bit words of a stream that starts at bit 0: word k = bits

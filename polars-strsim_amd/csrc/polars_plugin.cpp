@@ -93,7 +93,20 @@ void run(int measure, SeriesExport *inputs, size_t n_inputs, SeriesExport *ret, 
         const bool direct_call = n <= direct_rows();
         const uint64_t D = std::max<uint64_t>(1, std::min<uint64_t>(devs.size(), n / min_rows_per_device()));
         devs.resize((size_t)D);
-        run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, engine_parallel, devs, tm, ptimes);
+        bool combined = false;
+        if (direct_call) {
+            // a small call: when enough of them are in flight at once they share a launch (plugin_pipeline.h: Combiner)
+            const SmallCallGuard in_flight;
+            const CoalesceKnobs &ck = coalesce_knobs();
+            if (ck.on && D == 1 && !lit[0] && !lit[1] && n <= ck.rows && in_flight.before + 1 >= ck.min_inflight)
+                combined = combiner().run(measure, col, n, out, devs[0]);
+            if (!combined) {
+                combiner().direct_.fetch_add(1, std::memory_order_relaxed);
+                run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, engine_parallel, devs, tm, ptimes);
+            }
+        } else {
+            run_rows(measure, col, lit, n, out, out_pinned, T, direct_call, engine_parallel, devs, tm, ptimes);
+        }
     }
 
     // output validity = AND of the input validities (broadcast for a literal; a null literal is the all_null case)
@@ -171,6 +184,7 @@ const char *_polars_plugin_get_last_error_message(void) { return g_plugin_error.
 
 void _polars_plugin_strsim_staging_stats(uint64_t out[8]) { if (out) staging_pool().stats(out); }
 void _polars_plugin_strsim_staging_set_budget_mb(uint64_t megabytes) { staging_pool().set_budget(megabytes << 20); }
+void _polars_plugin_strsim_coalesce_stats(uint64_t out[4]) { if (out) combiner().stats(out); }
 
 #define POLARS_PLUGIN_DEFINE(name, id)                                                                          \
     void _polars_plugin_##name(SeriesExport *inputs, size_t n_inputs, const uint8_t *, size_t,                  \
@@ -346,6 +360,61 @@ POLARS_PLUGIN_API int _strsim_test_pack_grants(int engine_parallel, int n_calls,
         *helpers_out = g_helpers_out.load();
     }
     return g_helpers_out.load();
+}
+
+// (4) the staging pool under `budget_bytes`: one call's lease of a pipeline set (`need` = its estimate), `grow` bytes of staging
+// reserved in it (host memory in this build), held for `hold_us`, given back.  Called from many threads at once by the driver.
+// stats8 (optional): _polars_plugin_strsim_staging_stats' eight counters after the call.
+POLARS_PLUGIN_API int _strsim_test_staging_lease(uint64_t budget_bytes, uint64_t need, uint64_t grow, unsigned hold_us, uint64_t *stats8)
+{
+    try {
+        staging_pool().set_budget(budget_bytes);
+        {
+            PipeLease lease(need);
+            Pipe &P = lease.set->at(0);
+            P.slot[(need >> 3) % 3].h_val[0].reserve(grow);
+            memset(P.slot[(need >> 3) % 3].h_val[0].p, 0x5A, grow);
+            if (hold_us) std::this_thread::sleep_for(std::chrono::microseconds(hold_us));
+        }
+        if (stats8) staging_pool().stats(stats8);
+        return 0;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
+}
+
+// (5) one small call through the combiner (plugin_pipeline.h), with a CPU stand-in for the combined launch: out[i] = 4096 * (bytes of
+// row i of a) + (bytes of row i of b) + (first byte of a's row) / 256.  Owns and releases the two inputs like a plugin call.  Returns 1 when
+// the call was combined, 0 when it was not eligible, -1 on failure.
+static void test_combined_launch(const uint32_t *oa, const uint8_t *va, const uint32_t *ob, const uint8_t *, uint64_t rows, double *out)
+{
+    for (uint64_t i = 0; i < rows; ++i) {
+        const uint32_t la = oa[i + 1] - oa[i], lb = ob[i + 1] - ob[i];
+        out[i] = 4096.0 * la + lb + (la ? va[oa[i]] / 256.0 : 0.0);
+    }
+}
+POLARS_PLUGIN_API int _strsim_test_combine(SeriesExport *two_series, int measure, double *out, uint64_t *rows_out)
+{
+    InputGuard guard{two_series, 2};
+    try {
+        Column col[2];
+        describe(two_series[0], col[0]);
+        describe(two_series[1], col[1]);
+        if (col[0].rows != col[1].rows) fail("shape");
+        if (rows_out) *rows_out = col[0].rows;
+        static const bool stand_in = (combiner().test_launch = test_combined_launch, true); // (once: every caller thread comes through here)
+        (void)stand_in;
+        const SmallCallGuard in_flight;
+        return col[0].rows && combiner().run(measure, col, col[0].rows, out, 0) ? 1 : 0;
+    } catch (const PluginError &e) {
+        g_plugin_error = e.msg;
+    } catch (...) {
+        g_plugin_error = "unexpected failure";
+    }
+    return -1;
 }
 #endif // STRSIM_TEST_HOOKS
 

@@ -31,6 +31,8 @@ int _strsim_test_validity(SeriesExport *two_series, uint64_t *words, int64_t *nu
                           unsigned threads);
 int _strsim_test_pack_views(SeriesExport *series, uint64_t r0, uint64_t r1, uint64_t lbpr256, unsigned threads, uint8_t *views_out,
                             uint8_t *long_out, uint64_t long_cap, uint64_t *span_out, uint64_t *bytes_out);
+int _strsim_test_staging_lease(uint64_t budget_bytes, uint64_t need, uint64_t grow, unsigned hold_us, uint64_t *stats8);
+int _strsim_test_combine(SeriesExport *two_series, int measure, double *out, uint64_t *rows_out);
 }
 
 namespace {
@@ -296,6 +298,42 @@ void one_round(unsigned seed)
             CHECK(ok ? vals[r] == 1.5 : (all_null || vals[r] == 0.0), "value under a null slot, row %llu", (unsigned long long)r);
         }
         CHECK(nulls == want_nulls, "null count %lld / %lld", (long long)nulls, (long long)want_nulls);
+        CHECK(two[0].release == nullptr && two[1].release == nullptr, "the inputs were not released");
+    }
+    // ---- (3b) [r6] the staging pool: leases of pipeline sets from several caller threads at once under a budget that holds about two
+    //      of them (the calls WAIT for one another, idle sets are released); host memory stands in for pinned / device memory
+    {
+        const uint64_t budget = 24u << 20;
+        uint64_t st[8];
+        const uint64_t need = (uint64_t)(4 + rng() % 12) << 20, grow = (uint64_t)(1 + rng() % 10) << 20;
+        const int rc = _strsim_test_staging_lease(budget, need, grow, (unsigned)(rng() % 300), st);
+        CHECK(rc == 0, "staging lease rc %d (%s)", rc, _polars_plugin_get_last_error_message());
+        CHECK(st[2] == budget, "the pool's budget");
+        CHECK(st[3] >= 1 && st[4] <= st[3], "sets %llu, in use %llu", (unsigned long long)st[3], (unsigned long long)st[4]);
+    }
+    // ---- (3c) [r6] the combiner of concurrent small calls: this thread's call joins whatever batch the other threads have open; a CPU
+    //      stand-in for the combined launch writes a value that depends on the row's two lengths and first byte
+    {
+        const size_t m = 1 + rng() % 300;
+        std::vector<std::string> ra(rows.begin(), rows.begin() + (long)std::min(m, rows.size())), rb = ra;
+        for (auto &x : ra) if (x.size() > 200) x.resize(200);
+        for (auto &x : rb) { if (x.size() > 150) x.resize(150); if (!x.empty() && (rng() & 1)) x.pop_back(); }
+        std::vector<uint8_t> va(ra.size(), 1), vb(rb.size(), 1);
+        for (auto &x : va) x = (uint8_t)(rng() % 9 != 0);
+        Exported ea(layout, ra, va, rng), eb((Layout)((seed / 5) % 3), rb, vb, rng);
+        SeriesExport two[2];
+        ea.fill(two[0]);
+        eb.fill(two[1]);
+        std::vector<double> out(ra.size(), -1.0);
+        uint64_t rows_out = 0;
+        const int rc = _strsim_test_combine(two, (int)(seed % 5), out.data(), &rows_out);
+        CHECK(rc == 1, "combine rc %d (%s)", rc, _polars_plugin_get_last_error_message());
+        CHECK(rows_out == ra.size(), "rows");
+        for (size_t r = 0; r < ra.size(); ++r) {
+            const std::string a = va[r] ? ra[r] : std::string(), b = rb[r]; // (a null slot packs as an empty string)
+            const double want = 4096.0 * (double)a.size() + (double)b.size() + (a.empty() ? 0.0 : (unsigned char)a[0] / 256.0);
+            CHECK(out[r] == want, "combined call, row %llu: %f / %f", (unsigned long long)r, out[r], want);
+        }
         CHECK(two[0].release == nullptr && two[1].release == nullptr, "the inputs were not released");
     }
     // ---- (4) the helper-thread budget of engine-parallel calls, borrowed and returned by several caller threads at once: what is

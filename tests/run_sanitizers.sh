@@ -6,7 +6,7 @@
 #      under TSan, driven by tests/cpu_harness/plugin_sanitize_driver.cpp: several caller threads, each call fanning out over the
 #      packing pool
 #   3. the Python-driven packer tests (tests/test_plugin_packing_cpu.py) and the ABI ownership test against the ASan build
-# Logs: <out-dir>/sanitize_*.txt (default profiles/; committed as profiles/r4_sanitize_*.txt).  Exit code 0 = every run clean.
+# Logs: <out-dir>/sanitize_*.txt (default profiles/; committed as profiles/r6_sanitize_*.txt).  Exit code 0 = every run clean.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"
 OUT=${1:-profiles}; mkdir -p "$OUT"

@@ -27,6 +27,8 @@ KNOBS = [
     {"POLARS_STRSIM_VIEWS": "1"},
     {"POLARS_STRSIM_TRACE": "1"},
     {"POLARS_STRSIM_DEVICE": "0"},
+    {"POLARS_STRSIM_COALESCE": "1"},
+    {"POLARS_STRSIM_COALESCE": "1", "POLARS_STRSIM_COALESCE_MIN_INFLIGHT": "1", "POLARS_STRSIM_COALESCE_ROWS": "32768"},  # (small calls through the combiner: tests/test_plugin_coalesce_gpu.py)
     {"POLARS_STRSIM_STAGING_BUDGET_MB": "1"},   # (smaller than one call: every call's staging is released when it returns)
     {"POLARS_STRSIM_STAGING_BUDGET_MB": "0"},   # (no budget)
     {"POLARS_STRSIM_DEVICES": "0,0", "POLARS_STRSIM_MIN_ROWS_PER_DEVICE": "20000"},
