@@ -38,5 +38,13 @@ cut -c1-400 $OUT/bench_2rank_one_gpu.jsonl
 STEPS=10 WARMUP=5 bash bench_support/jobs/n8_first_contact.sh > $OUT/n8_first_contact_on_one_gpu.txt 2>&1
 python tests/helpers/staging_child.py 32 4000000 > $OUT/staging_32_threads_default_budget.json 2>/dev/null
 POLARS_STRSIM_STAGING_BUDGET_MB=1024 python tests/helpers/staging_child.py 32 4000000 > $OUT/staging_32_threads_1gib.json 2>/dev/null
-python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
+# concurrent small calls: the C ABI alone, then the plugin ABI without and with the (opt-in) combiner
+g++ -O2 -std=c++17 -pthread -Iinclude bench_support/micro/small_call_threads.cpp -o bench_support/micro/small_call_threads polars-strsim_amd/polars_strsim/libpolars_strsim_amd.so -Wl,-rpath,$PWD/polars-strsim_amd/polars_strsim
+bench_support/micro/small_call_threads 3000 > $OUT/small_call_threads.txt 2>/dev/null
+g++ -O2 -std=c++17 -pthread -Iinclude bench_support/micro/plugin_small_threads.cpp -o bench_support/micro/plugin_small_threads polars-strsim_amd/polars_strsim/libpolars_strsim_amd.so -Wl,-rpath,$PWD/polars-strsim_amd/polars_strsim
+for mode in "POLARS_STRSIM_COALESCE=0" "POLARS_STRSIM_COALESCE=1"; do
+  echo "== $mode" >> $OUT/plugin_small_threads.txt
+  env $mode bench_support/micro/plugin_small_threads 2000 >> $OUT/plugin_small_threads.txt 2>/dev/null
+done
+python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; grep -a "passed\|failed" $OUT/pytest_gpu.txt | tail -2
 grep -h "k_lane\|k_wave" $OUT/prof_cfg2.txt | head -4; grep -h "traffic.json" $OUT/prof_cfg*.txt
