@@ -245,6 +245,7 @@ struct PipeSet {
     uint64_t last_used = 0; // the pool's clock when the set came back
     Pipe &at(size_t i) { while (p.size() <= i) p.push_back(new Pipe); return *p[i]; }
     uint64_t live() const { uint64_t b = 0; for (const Pipe *q : p) b += q->live(); return b; }
+    bool has_context() const { for (const Pipe *q : p) if (q->ctx) return true; return false; }
     void close()
     {   // (releasing a pipeline selects its device: put the calling thread's own choice back)
         int cur = -1;
@@ -324,9 +325,16 @@ class StagingPool {
                 lru->close();
                 ++released_;
             }
-            // (sets that hold nothing any more are dropped, so the list does not grow with every thread the engine ever had)
+            // (sets that hold nothing any more -- no staging and no device context: released above, or never used -- are dropped, so the
+            //  list does not grow with every thread the engine ever had.  A set with a context but no buffers stays: a combined launch of
+            //  small calls leases exactly that, and a context costs ~6 ms to make)
             for (size_t i = 0; i < sets_.size();)
-                if (!sets_[i]->in_use && sets_[i]->live() == 0 && sets_.size() > 1 && sets_[i] != s) { delete sets_[i]; sets_.erase(sets_.begin() + (long)i); } else ++i;
+                if (!sets_[i]->in_use && sets_[i]->live() == 0 && !sets_[i]->has_context() && sets_.size() > 1 && sets_[i] != s) {
+                    delete sets_[i];
+                    sets_.erase(sets_.begin() + (long)i);
+                } else {
+                    ++i;
+                }
         }
         cv_.notify_all();
     }
