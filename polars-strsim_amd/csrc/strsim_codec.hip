@@ -186,6 +186,11 @@ __global__ void k_encode_packed(const double *__restrict__ vals, uint64_t n, uns
 // DECODE_LDS_ENTRIES values (Levenshtein: 325, Jaccard / Dice: 631) is read from LDS instead of through the address unit.
 // Escaped rows are left untouched (patched from the exception list).
 constexpr uint32_t DECODE_LDS_ENTRIES = 2048;
+#ifndef STRSIM_DECODE_ROWS_PER_THREAD
+#define STRSIM_DECODE_ROWS_PER_THREAD 2
+#endif
+constexpr int DECODE_RPT = STRSIM_DECODE_ROWS_PER_THREAD;
+static_assert(DECODE_RPT == 2 || DECODE_RPT == 4, "pairs of rows: one or two 16-byte stores per thread");
 template <bool LDS_TABLE>
 __device__ __forceinline__ void decode_tiles(const unsigned long long *__restrict__ words, uint64_t n, uint32_t per, uint32_t bits,
                                              uint32_t magic32, double *__restrict__ out, const double *__restrict__ table,
@@ -194,10 +199,41 @@ __device__ __forceinline__ void decode_tiles(const unsigned long long *__restric
     const unsigned long long esc = (1ull << bits) - 1ull;
     const uint32_t tile_rows = per * 256u, tid = threadIdx.x;
     const uint64_t ntiles = (n + tile_rows - 1u) / tile_rows;
+    // [r6] two rows per thread and ONE 16-byte store for the pair when neither row escaped (escapes are rare: rows outside the table) --
+    // 8-byte-per-lane stores reach ~3.2 TB/s here, 16-byte ones more (the root of a gather at N = 8 writes 700 MB per column and step:
+    // profiles/r6_root_rehearsal.txt).  Only when the pairs are 16-byte aligned (tile_rows is even; `out` decides: uniform).
+    const bool pairs = (reinterpret_cast<uintptr_t>(out) & 15u) == 0u && (tile_rows & 1u) == 0u;
     for (uint64_t tile = tile0; tile < ntiles; tile += tile_step) {
         const uint64_t row0 = tile * tile_rows;
         const unsigned long long *__restrict__ const wt = words + tile * 256u;
         const uint32_t left = (uint32_t)(n - row0 < (uint64_t)tile_rows ? n - row0 : (uint64_t)tile_rows);
+        if (pairs) {
+            typedef double double2_a16 __attribute__((ext_vector_type(2), aligned(16)));
+            // STRSIM_DECODE_ROWS_PER_THREAD (2 or 4) consecutive rows per thread: one or two 16-byte stores
+            for (uint32_t x = (uint32_t)DECODE_RPT * tid; x < left; x += 256u * (uint32_t)DECODE_RPT) {
+                uint32_t c[DECODE_RPT];
+                double v[DECODE_RPT];
+#pragma unroll
+                for (int q = 0; q < DECODE_RPT; ++q) {
+                    const uint32_t xq = x + (uint32_t)q, wl = __umulhi(xq, magic32), k = xq - wl * per;
+                    c[q] = xq < left ? (uint32_t)((wt[wl] >> (k * bits)) & esc) : (uint32_t)esc; // (a row that does not exist: "escaped")
+                }
+#pragma unroll
+                for (int q = 0; q < DECODE_RPT; ++q) v[q] = c[q] != (uint32_t)esc ? (LDS_TABLE ? s_tab[c[q]] : table[c[q]]) : 0.0;
+#pragma unroll
+                for (int q = 0; q < DECODE_RPT; q += 2) {
+                    if (c[q] != (uint32_t)esc && c[q + 1] != (uint32_t)esc) {
+                        double2_a16 w;
+                        w.x = v[q]; w.y = v[q + 1];
+                        *reinterpret_cast<double2_a16 *>(out + row0 + x + (uint32_t)q) = w;
+                    } else {
+                        if (c[q] != (uint32_t)esc) out[row0 + x + (uint32_t)q] = v[q];
+                        if (c[q + 1] != (uint32_t)esc) out[row0 + x + (uint32_t)q + 1u] = v[q + 1];
+                    }
+                }
+            }
+            continue;
+        }
         for (uint32_t x = tid; x < left; x += 256u) {
             const uint32_t wl = __umulhi(x, magic32); // x / per
             const uint32_t k = x - wl * per;
